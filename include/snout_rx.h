@@ -1,0 +1,147 @@
+/*
+ * snout_rx.h — C ABI of libsnout_rx.so, the MI355X (gfx950) IQ -> packets receive path.
+ *
+ * This is the drop-in boundary for the two process boundaries the reference crosses on its
+ * receive hot path:
+ *
+ *   BTLE   : the `btle_rx` child process started at  snout/util/btle.py:53,63-69
+ *            (argv `-c CH -g 6 -a 8e89bed6 -k 555555`), whose stdout lines are parsed by
+ *            snout/core/message.py:205-237.  -> snout_rx_create(proto=SNOUT_PROTO_BTLE) +
+ *            snout_rx_process*() + snout_btle_format_line().
+ *   Zigbee : the GNU Radio flowgraph snout/modulations/Zigbee/hackrf/Zigbee_rx/top_block.py:52-89
+ *            (quadrature_demod_cf -> x - single_pole_iir(x) -> clock_recovery_mm_ff ->
+ *            ieee802_15_4.packet_sink(10) -> epy_block_0 -> rftap_encap(2,195,'') -> UDP 52002).
+ *            -> snout_rx_create(proto=SNOUT_PROTO_ZIGBEE) + snout_rx_process*() +
+ *            snout_rftap_encap().
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP types in signatures; a HIP stream is
+ * passed as void*).  Every function returns 0 on success or a negative SNOUT_E* code.  The caller
+ * owns every buffer it passes.  A handle is not thread-safe; different handles are independent.
+ * No callbacks.  The library never falls back to a CPU path: without a usable gfx950 device
+ * snout_rx_create() fails with SNOUT_ENODEV.
+ */
+#ifndef SNOUT_RX_H
+#define SNOUT_RX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNOUT_ABI_VERSION 1u
+
+/* protocols (snout/core/protocols/__init__.py:2-27 names them BTLE / ZIGBEE) */
+#define SNOUT_PROTO_BTLE   0u
+#define SNOUT_PROTO_ZIGBEE 1u
+
+/* error codes */
+#define SNOUT_OK          0
+#define SNOUT_EINVAL     -1   /* bad argument / configuration                      */
+#define SNOUT_ENODEV     -2   /* no usable HIP device (no CPU fallback exists)     */
+#define SNOUT_ENOMEM     -3   /* device or host allocation failed                  */
+#define SNOUT_EHIP       -4   /* a HIP runtime call failed (see snout_last_error)  */
+#define SNOUT_EOVERFLOW  -5   /* more hits / packets than the configured capacity  */
+#define SNOUT_ERANGE     -6   /* segment too long for 32-bit in-segment indices    */
+
+/* snout_rx_soft() stage selectors (test-only taps of soft intermediates)   */
+#define SNOUT_STAGE_BTLE_BITS     0u  /* a1: hard bits, one uint8 (0/1) per sample, as floats  */
+#define SNOUT_STAGE_CHAN_IQ       1u  /* PFB output, channel-major interleaved cf32            */
+#define SNOUT_STAGE_ZB_DISCRIM    2u  /* a4: quadrature_demod_cf output                        */
+#define SNOUT_STAGE_ZB_DCREMOVED  3u  /* a5: x - single_pole_iir(x)                            */
+#define SNOUT_STAGE_ZB_CHIPS      4u  /* a6: clock_recovery_mm_ff output (lane 0 of channel 0) */
+
+typedef struct snout_rx_cfg {
+    uint32_t abi_version;     /* SNOUT_ABI_VERSION                                              */
+    uint32_t proto;           /* SNOUT_PROTO_*                                                  */
+    uint32_t n_channels;      /* 1: input is one narrowband channel at 4 Msps (no channelizer).
+                                 M>1: wideband input, M-branch polyphase channelizer, 2x oversampled
+                                 (decimation M/2): BTLE M=40 (80 Msps), Zigbee M=16 (32 Msps)    */
+    uint32_t taps_per_branch; /* P of the PFB prototype (M*P taps); 0 -> 16                     */
+    uint32_t channel;         /* n_channels==1: protocol channel number of the input
+                                 (BTLE 0..39 -> whitening seed, `-c` of btle.py:64;
+                                  Zigbee 11..26, top_block.py:94-96). Ignored for wideband.     */
+    uint32_t access_addr;     /* BTLE `-a` (btle.py:66); 0 -> 0x8E89BED6                         */
+    uint32_t crc_init;        /* BTLE `-k` (btle.py:67); 0 -> 0x555555                           */
+    uint32_t chip_threshold;  /* packet_sink(threshold) (top_block.py:67); 0 -> 10               */
+    uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 -> 16384          */
+    uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 2048 */
+    uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
+    int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
+    uint32_t reserved[4];
+} snout_rx_cfg;
+
+/* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
+typedef struct snout_pkt {
+    uint64_t sample_index;    /* BTLE: first sample of the access address; Zigbee: sample at which
+                                 the first preamble symbol was recognised. In channel samples,
+                                 plus first_sample_index of the call.                            */
+    uint32_t proto;           /* SNOUT_PROTO_*                                                   */
+    uint16_t channel;         /* protocol channel number (BTLE 0..39, Zigbee 11..26)             */
+    uint16_t len;             /* valid bytes in bytes[]: BTLE 2+payload+3 (header, payload, CRC),
+                                 Zigbee PSDU length (FCS included, not checked — as packet_sink)  */
+    uint8_t  crc_ok;          /* BTLE: 1 if CRC24 matches (btle_rx prints CRC0). Zigbee: FCS-16 ok */
+    uint8_t  lqi;             /* Zigbee LQI as packet_sink computes it; BTLE 0                   */
+    uint8_t  pdu_type;        /* BTLE header & 0x0F                                              */
+    uint8_t  flags;           /* BTLE: TxAdd | RxAdd<<1                                          */
+    uint32_t aux;             /* BTLE: sample phase 0..3 of the hit; Zigbee: lane id             */
+    uint8_t  bytes[136];
+} snout_pkt;
+
+/* Device-time breakdown of the last snout_rx_process*() call, measured with HIP events on the
+ * stream the kernels were launched on. */
+typedef struct snout_rx_prof {
+    float    ms_total;        /* first kernel start -> records landed in host memory             */
+    float    ms_dominant;     /* the dominant streaming kernel alone                             */
+    uint32_t dominant_launches;
+    uint32_t n_hits;          /* candidate hits before resolution (BTLE) / lanes (Zigbee)        */
+    uint64_t bytes_algorithmic; /* 8 B x input samples + 160 B x packets            */
+    char     dominant_name[48];
+} snout_rx_prof;
+
+typedef struct snout_rx snout_rx;
+
+int  snout_rx_create (const snout_rx_cfg* cfg, snout_rx** out);
+void snout_rx_destroy(snout_rx* h);
+
+/* One capture segment, synchronous. iq = interleaved cf32 (re,im), n_samples complex samples.
+ * Packets are written in ascending (channel, sample_index) order. *n_out receives the number of
+ * packets found (may exceed cap -> SNOUT_EOVERFLOW, first cap records valid).
+ *
+ * snout_rx_process      : iq in HOST memory; copied H->D (PCIe-inclusive path).
+ * snout_rx_process_dev  : iq already resident in DEVICE memory (HBM); hip_stream is a hipStream_t
+ *                         (NULL = the legacy default stream). out is HOST memory. */
+int  snout_rx_process    (snout_rx* h, const float* iq_host, uint64_t n_samples,
+                          uint64_t first_sample_index, snout_pkt* out, uint64_t cap, uint64_t* n_out);
+int  snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
+                          uint64_t first_sample_index, void* hip_stream,
+                          snout_pkt* out, uint64_t cap, uint64_t* n_out);
+
+/* Copy a soft intermediate of the LAST processed segment to host floats (tests only). */
+int  snout_rx_soft   (snout_rx* h, uint32_t stage, uint32_t channel_slot,
+                      float* out, uint64_t cap, uint64_t* n_out);
+int  snout_rx_profile(snout_rx* h, snout_rx_prof* out);
+
+/* Host-side formatters for the two consumer contracts. */
+/* btle_rx stdout grammar (snout/core/message.py:214-215,226-236). Returns bytes written
+ * (excluding NUL) or negative error. */
+int  snout_btle_format_line(const snout_pkt* p, double fs_hz, double t0_epoch, uint32_t pkt_number,
+                            uint32_t access_addr, char* dst, size_t cap);
+/* RFtap header + MPDU, as rftap_encap(2,195,'') emits with meta{qual=lqi/255}
+ * (top_block.py:53, epy_block_0.py:20-24). Returns datagram length or negative error. */
+int  snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap);
+
+/* Channel plans (a10). */
+double   snout_zigbee_center_hz(uint32_t channel);   /* 1e6*(2400+5*(ch-10)), top_block.py:56,94-96 */
+double   snout_btle_center_hz(uint32_t channel);     /* 37->2402, 38->2426, 39->2480, data channels */
+int32_t  snout_btle_rf_to_channel(uint32_t rf_index);/* RF k (2402+2k MHz) -> BLE channel index    */
+
+const char* snout_strerror(int code);
+const char* snout_last_error(void);  /* thread-local detail string of the last failure */
+uint32_t    snout_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNOUT_RX_H */

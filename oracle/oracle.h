@@ -1,0 +1,30 @@
+/*
+ * oracle.h — declarations of the CPU oracle (TEST INFRASTRUCTURE ONLY; see oracle_btle.c).
+ * The record layout is the ABI one from include/snout_rx.h.
+ */
+#ifndef SNOUT_ORACLE_H
+#define SNOUT_ORACLE_H
+#include <stdint.h>
+#include "../include/snout_rx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- BTLE (oracle_btle.c) ---- */
+void     oracle_btle_whiten_seq(uint32_t channel, uint8_t* out, int nbytes);
+uint32_t oracle_btle_crc24(const uint8_t* data, int n, uint32_t init);
+uint32_t oracle_btle_crc24_table(const uint8_t* data, int n, uint32_t init);
+void     oracle_btle_crc_bytes(uint32_t r, uint8_t out[3]);
+uint64_t oracle_btle_bits(const float* iq, uint64_t n_samples, uint8_t* bits);
+uint64_t oracle_btle_all_hits(const uint8_t* bits, uint64_t nb, uint32_t access_addr,
+                              uint64_t* hits, uint64_t cap);
+int      oracle_btle_segment(const float* iq, uint64_t n_samples, uint64_t first_sample_index,
+                             uint32_t channel, uint32_t access_addr, uint32_t crc_init,
+                             snout_pkt* out, uint64_t cap, uint64_t* n_out,
+                             uint64_t* hits_out, uint64_t hits_cap, uint64_t* n_hits_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

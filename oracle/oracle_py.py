@@ -1,0 +1,131 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Builds the library with the committed Makefile if it is missing or stale.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+class SnoutPkt(C.Structure):
+    _fields_ = [("sample_index", C.c_uint64), ("proto", C.c_uint32), ("channel", C.c_uint16),
+                ("len", C.c_uint16), ("crc_ok", C.c_uint8), ("lqi", C.c_uint8),
+                ("pdu_type", C.c_uint8), ("flags", C.c_uint8), ("aux", C.c_uint32),
+                ("bytes", C.c_uint8 * 136)]
+
+
+assert C.sizeof(SnoutPkt) == 160
+
+PKT_DTYPE = np.dtype([("sample_index", "<u8"), ("proto", "<u4"), ("channel", "<u2"),
+                      ("len", "<u2"), ("crc_ok", "u1"), ("lqi", "u1"), ("pdu_type", "u1"),
+                      ("flags", "u1"), ("aux", "<u4"), ("bytes", "u1", (136,))])
+assert PKT_DTYPE.itemsize == 160
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE)
+            if f.endswith((".c", ".h", ".inc")) or f == "Makefile"]
+    srcs.append(os.path.join(_HERE, "..", "include", "snout_rx.h"))
+    stale = force or not os.path.exists(_LIB) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "liboracle.so"], check=True)
+    return _LIB
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        u8p, u64p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+        _lib.oracle_btle_whiten_seq.argtypes = [C.c_uint32, u8p, C.c_int]
+        _lib.oracle_btle_whiten_seq.restype = None
+        _lib.oracle_btle_crc24.argtypes = [u8p, C.c_int, C.c_uint32]
+        _lib.oracle_btle_crc24.restype = C.c_uint32
+        _lib.oracle_btle_crc24_table.argtypes = [u8p, C.c_int, C.c_uint32]
+        _lib.oracle_btle_crc24_table.restype = C.c_uint32
+        _lib.oracle_btle_crc_bytes.argtypes = [C.c_uint32, u8p]
+        _lib.oracle_btle_crc_bytes.restype = None
+        _lib.oracle_btle_bits.argtypes = [f32p, C.c_uint64, u8p]
+        _lib.oracle_btle_bits.restype = C.c_uint64
+        _lib.oracle_btle_all_hits.argtypes = [u8p, C.c_uint64, C.c_uint32, u64p, C.c_uint64]
+        _lib.oracle_btle_all_hits.restype = C.c_uint64
+        _lib.oracle_btle_segment.argtypes = [f32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_void_p, C.c_uint64, u64p,
+                                             u64p, C.c_uint64, u64p]
+        _lib.oracle_btle_segment.restype = C.c_int
+    return _lib
+
+
+def _f32(iq: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(iq)
+    if a.dtype == np.complex64:
+        a = a.view(np.float32)
+    assert a.dtype == np.float32
+    return a
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def btle_whiten_seq(channel: int, n: int = 42) -> bytes:
+    out = np.zeros(n, dtype=np.uint8)
+    lib().oracle_btle_whiten_seq(channel, _p(out, C.c_uint8), n)
+    return out.tobytes()
+
+
+def btle_crc24(data: bytes, init: int = 0x555555, table: bool = False) -> int:
+    a = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    f = lib().oracle_btle_crc24_table if table else lib().oracle_btle_crc24
+    return int(f(_p(a, C.c_uint8), a.size, init))
+
+
+def btle_crc_bytes(r: int) -> bytes:
+    out = np.zeros(3, dtype=np.uint8)
+    lib().oracle_btle_crc_bytes(r, _p(out, C.c_uint8))
+    return out.tobytes()
+
+
+def btle_bits(iq: np.ndarray) -> np.ndarray:
+    a = _f32(iq)
+    n = a.size // 2
+    bits = np.zeros(max(n, 1), dtype=np.uint8)
+    nb = lib().oracle_btle_bits(_p(a, C.c_float), n, _p(bits, C.c_uint8))
+    return bits[:nb]
+
+
+def btle_all_hits(bits: np.ndarray, aa: int = 0x8E89BED6) -> np.ndarray:
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    cap = max(1024, bits.size // 64)
+    hits = np.zeros(cap, dtype=np.uint64)
+    n = lib().oracle_btle_all_hits(_p(bits, C.c_uint8), bits.size, aa, _p(hits, C.c_uint64), cap)
+    assert n <= cap
+    return hits[:n]
+
+
+def btle_segment(iq: np.ndarray, channel: int = 37, aa: int = 0x8E89BED6, crc_init: int = 0x555555,
+                 first_sample_index: int = 0, cap: int = 0):
+    a = _f32(iq)
+    n = a.size // 2
+    cap = cap or max(64, n // 512)
+    out = np.zeros(cap, dtype=PKT_DTYPE)
+    n_out = C.c_uint64(0)
+    n_hits = C.c_uint64(0)
+    hits = np.zeros(cap * 4, dtype=np.uint64)
+    rc = lib().oracle_btle_segment(_p(a, C.c_float), n, first_sample_index, channel, aa, crc_init,
+                                   out.ctypes.data_as(C.c_void_p), cap, C.byref(n_out),
+                                   _p(hits, C.c_uint64), hits.size, C.byref(n_hits))
+    assert rc == 0, rc
+    return out[:n_out.value], hits[:min(n_hits.value, hits.size)]

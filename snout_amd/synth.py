@@ -1,0 +1,170 @@
+"""Deterministic synthetic IQ generators (numpy) for the receive path.
+
+These are the *signal definitions* the receive path is measured on:
+
+* BTLE advertising packets -> 1 Mbit/s GFSK (BT 0.5, h 0.5) at 4 samples/symbol, the rate
+  ``btle_rx`` runs at (reference call site ``snout/util/btle.py:63-69``; access address and CRC
+  init are the ``-a 8e89bed6 -k 555555`` of that call).
+* IEEE 802.15.4 O-QPSK frames built the way the reference's own transmitter flowgraph does it
+  (``snout/modulations/Zigbee/hackrf/Zigbee_tx/top_block.py:59-71``): nibble -> 16 complex chips
+  (even chip on I, odd chip on Q) -> repeat 4 -> half-sine ``[0, sin(pi/4), 1, sin(3pi/4)]`` ->
+  Q delayed by 2 samples, i.e. 4 samples per complex chip pair = 2 samples per chip at 4 Msps.
+* A wideband compositor that places narrowband channels on the bin centres of the polyphase
+  channelizer.
+
+Whitening / CRC here are written independently of ``oracle/`` (bit-serial, straight from the
+Bluetooth Core Spec Vol 6 Part B §3.1-3.2) so tests can cross-check three implementations.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+BTLE_ADV_AA = 0x8E89BED6
+BTLE_ADV_CRC_INIT = 0x555555
+BTLE_SPS = 4
+
+ADV_PDU_TYPES = ["ADV_IND", "ADV_DIRECT_IND", "ADV_NONCONN_IND", "SCAN_REQ",
+                 "SCAN_RSP", "CONNECT_REQ", "ADV_SCAN_IND"]
+
+
+# ------------------------------------------------------------------------------------------------
+# BTLE bit-level
+# ------------------------------------------------------------------------------------------------
+def btle_whiten_bits(channel: int, nbits: int) -> np.ndarray:
+    """Whitening bit sequence: LFSR x^7+x^4+1, position 0 = 1, positions 1..6 = channel MSB..LSB."""
+    reg = [1] + [(channel >> (5 - i)) & 1 for i in range(6)]
+    out = np.empty(nbits, dtype=np.uint8)
+    for i in range(nbits):
+        o = reg[6]
+        out[i] = o
+        reg = [o, reg[0], reg[1], reg[2], reg[3] ^ o, reg[4], reg[5]]
+    return out
+
+
+def bytes_to_bits_lsb(data: bytes) -> np.ndarray:
+    a = np.frombuffer(bytes(data), dtype=np.uint8)
+    return np.unpackbits(a, bitorder="little")
+
+
+def bits_to_bytes_lsb(bits: np.ndarray) -> bytes:
+    return np.packbits(np.asarray(bits, dtype=np.uint8), bitorder="little").tobytes()
+
+
+def btle_crc24_bits(bits: Sequence[int], init: int = BTLE_ADV_CRC_INIT) -> List[int]:
+    """CRC24 (x^24+x^10+x^9+x^6+x^4+x^3+x+1) over a bit sequence; returns the 24 CRC bits in
+    transmit order (register position 23 first)."""
+    r = init & 0xFFFFFF
+    for b in bits:
+        t = (r >> 23) & 1
+        r = (r << 1) & 0xFFFFFF
+        if t != int(b):
+            r ^= 0x00065B
+    return [(r >> (23 - i)) & 1 for i in range(24)]
+
+
+def btle_adv_pdu(pdu_type: int, adva: bytes, advdata: bytes = b"", txadd: int = 0,
+                 rxadd: int = 0) -> bytes:
+    """Advertising-channel PDU (header + payload). ``adva`` is given MSB first (as btle_rx
+    prints it, message.py:214) and is sent LSB first."""
+    assert len(adva) == 6
+    payload = bytes(adva[::-1]) + bytes(advdata)
+    assert 6 <= len(payload) <= 37
+    h0 = (pdu_type & 0x0F) | ((txadd & 1) << 6) | ((rxadd & 1) << 7)
+    return bytes([h0, len(payload)]) + payload
+
+
+def btle_air_bits(pdu: bytes, channel: int, aa: int = BTLE_ADV_AA,
+                  crc_init: int = BTLE_ADV_CRC_INIT) -> np.ndarray:
+    """Preamble + access address + whitened(PDU + CRC), in transmit order."""
+    pdu_bits = bytes_to_bits_lsb(pdu)
+    crc_bits = np.array(btle_crc24_bits(pdu_bits, crc_init), dtype=np.uint8)
+    body = np.concatenate([pdu_bits, crc_bits])
+    body ^= btle_whiten_bits(channel, body.size)
+    aa_bits = np.array([(aa >> i) & 1 for i in range(32)], dtype=np.uint8)
+    # alternating preamble whose first bit equals the first (LSB) bit of the access address
+    first = aa_bits[0]
+    pre = np.array([first ^ (i & 1) for i in range(8)], dtype=np.uint8)
+    return np.concatenate([pre, aa_bits, body])
+
+
+# ------------------------------------------------------------------------------------------------
+# GFSK modulator
+# ------------------------------------------------------------------------------------------------
+def _gauss_taps(bt: float, sps: int, span: int) -> np.ndarray:
+    t = (np.arange(span * sps + 1) - span * sps / 2.0) / sps
+    sigma = math.sqrt(math.log(2.0)) / (2.0 * math.pi * bt)
+    g = np.exp(-0.5 * (t / sigma) ** 2)
+    return g / g.sum()
+
+
+def gfsk_modulate(bits: np.ndarray, sps: int = BTLE_SPS, bt: float = 0.5, h: float = 0.5,
+                  pad_symbols: int = 4) -> np.ndarray:
+    """bits -> complex64 baseband, constant envelope. Bit 1 = positive frequency deviation."""
+    nrz = 2.0 * np.asarray(bits, dtype=np.float64) - 1.0
+    nrz = np.concatenate([np.zeros(pad_symbols), nrz, np.zeros(pad_symbols)])
+    up = np.repeat(nrz, sps)
+    f = np.convolve(up, _gauss_taps(bt, sps, 4), mode="same")
+    phase = np.cumsum(f) * (math.pi * h / sps)
+    return np.exp(1j * phase).astype(np.complex64)
+
+
+@dataclass
+class TruthPacket:
+    proto: int
+    channel: int
+    sample_index: int      # first sample of the access address (BTLE) / of the preamble (Zigbee)
+    payload: bytes         # BTLE: PDU (header+payload); Zigbee: PSDU incl. FCS
+    extra: dict = field(default_factory=dict)
+
+
+def btle_random_pdu(rng: np.random.Generator, max_advdata: int = 31) -> bytes:
+    pdu_type = int(rng.choice([0, 2]))              # ADV_IND / ADV_NONCONN_IND
+    adva = bytes(rng.integers(0, 256, 6, dtype=np.uint8))
+    adva = bytes([adva[0] | 0xC0]) + adva[1:]       # random static address
+    n = int(rng.integers(0, max_advdata + 1))
+    advdata = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    return btle_adv_pdu(pdu_type, adva, advdata, txadd=1, rxadd=0)
+
+
+def btle_capture(n_samples: int, channel: int = 37, seed: int = 1, mean_gap: float = 20000.0,
+                 sigma: float = 0.05, cfo_max_hz: float = 50e3, fs: float = 4e6,
+                 amplitude: float = 1.0, n_packets: Optional[int] = None,
+                 tail_guard: int = 2048, noise: bool = True,
+                 max_advdata: int = 31) -> Tuple[np.ndarray, List[TruthPacket]]:
+    """Single-channel capture at 4 samples/symbol: AWGN everywhere + GFSK advertising packets
+    separated by exponential gaps (SURVEY §8d cfg #2). Returns (complex64[n_samples], truth)."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros(n_samples, dtype=np.complex64)
+    truth: List[TruthPacket] = []
+    pos = int(rng.exponential(mean_gap)) + 256
+    pad = 4
+    while True:
+        if n_packets is not None and len(truth) >= n_packets:
+            break
+        pdu = btle_random_pdu(rng, max_advdata)
+        bits = btle_air_bits(pdu, channel)
+        wave = gfsk_modulate(bits, pad_symbols=pad)
+        if pos + wave.size + tail_guard > n_samples:
+            break
+        cfo = rng.uniform(-cfo_max_hz, cfo_max_hz)
+        ph0 = rng.uniform(0, 2 * math.pi)
+        n = np.arange(wave.size)
+        rot = np.exp(1j * (2 * math.pi * cfo / fs * n + ph0)).astype(np.complex64)
+        x[pos:pos + wave.size] += (amplitude * wave * rot).astype(np.complex64)
+        aa_start = pos + (pad + 8) * BTLE_SPS
+        truth.append(TruthPacket(0, channel, aa_start, pdu, {"cfo": cfo}))
+        pos += wave.size + int(rng.exponential(mean_gap))
+    if noise and sigma > 0:
+        x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+              ).astype(np.complex64)
+    return x, truth
+
+
+def to_interleaved(x: np.ndarray) -> np.ndarray:
+    """complex64[n] -> float32[2n] view (re, im interleaved), the on-disk/ABI layout."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    return x.view(np.float32)
