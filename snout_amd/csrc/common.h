@@ -1,0 +1,77 @@
+// common.h — shared declarations of libsnout_rx.so internals (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <string.h>
+#include "../../include/snout_rx.h"
+
+namespace snout {
+
+// ---- error plumbing -----------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+#define SNOUT_HIP(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::snout::set_last_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                    __FILE__, __LINE__);                                  \
+            return SNOUT_EHIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+// ---- geometry of the BTLE streaming kernel ----------------------------------------------------
+constexpr int kWave = 64;
+constexpr int kIterSamples = 256;   // samples one wave consumes per iteration (4 per lane)
+constexpr int kChunkIters = 64;     // iterations per chunk -> 16384 samples per wave
+constexpr int kChunkSamples = kIterSamples * kChunkIters;
+constexpr int kBtleMaxSpan = 128 + 32 * (2 + 37 + 3);   // AA start -> end of CRC, samples
+
+// Candidate produced by the decode kernel, consumed by resolve/emit.
+struct BtleCand {
+    uint32_t n_hit;      // in-segment sample index of the last access-address bit
+    uint32_t next;       // sample index at which the sequential search would resume
+    uint16_t slot;       // channel slot
+    uint8_t  status;     // 0 ok, 1 header truncated, 2 bad length, 3 payload truncated
+    uint8_t  accept;     // set by resolve
+};
+static_assert(sizeof(BtleCand) == 12, "BtleCand layout");
+
+// A growable device buffer.
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+
+constexpr int kChunkHitCap = 32;    // candidate hits one 16384-sample chunk can hold
+
+// BTLE pipeline state shared by the narrowband and the channelized front ends (btle.hip).
+struct BtleCtx {
+    uint32_t n_slots = 0, aa = 0, crc_init = 0, max_hits_cfg = 0;
+    uint32_t n_chunks = 0, max_cand = 0, last_n_cand = 0;
+    uint64_t plane_stride = 0;
+    DevBuf d_planes, d_chunk_cnt, d_chunk_off, d_chunk_hits, d_cand, d_stage, d_accept, d_out_off,
+        d_out, d_whiten, d_slot_channel, d_totals;
+    uint32_t* h_totals = nullptr;
+    snout_pkt* h_out = nullptr;
+    uint64_t h_out_cap = 0;
+    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_t1 = nullptr;
+
+    int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t aa, uint32_t crc_init,
+             uint32_t max_hits);
+    void destroy();
+    int reserve(uint64_t n_channel_samples);
+    int launch_demod_corr(const float* d_iq, uint64_t n, hipStream_t st);
+    int launch_corr_planes(uint64_t n, hipStream_t st);
+    int finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt* out, uint64_t cap,
+               uint64_t* n_out);
+};
+
+}  // namespace snout

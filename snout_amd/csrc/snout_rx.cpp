@@ -1,0 +1,219 @@
+// snout_rx.cpp — the C ABI of libsnout_rx.so (include/snout_rx.h): handle management, argument
+// checking, H->D staging for the host-pointer entry point, profiling read-back.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <new>
+
+namespace snout {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        set_last_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        p = nullptr;
+        return SNOUT_ENOMEM;
+    }
+    cap = want;
+    return 0;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+}  // namespace snout
+
+using namespace snout;
+
+struct snout_rx {
+    snout_rx_cfg cfg;
+    int device = 0;
+    BtleCtx btle;
+    DevBuf d_iq;              // staging for snout_rx_process (host input)
+    uint64_t last_n = 0;
+    uint64_t last_pkts = 0;
+    bool have_prof = false;
+};
+
+extern "C" {
+
+uint32_t snout_abi_version(void) { return SNOUT_ABI_VERSION; }
+
+const char* snout_last_error(void) { return g_err; }
+
+const char* snout_strerror(int code)
+{
+    switch (code) {
+        case SNOUT_OK: return "ok";
+        case SNOUT_EINVAL: return "invalid argument";
+        case SNOUT_ENODEV: return "no usable HIP device (libsnout_rx has no CPU fallback)";
+        case SNOUT_ENOMEM: return "out of memory";
+        case SNOUT_EHIP: return "HIP runtime error";
+        case SNOUT_EOVERFLOW: return "capacity exceeded";
+        case SNOUT_ERANGE: return "segment too long";
+        default: return "unknown error";
+    }
+}
+
+int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
+{
+    if (!cfg || !out) return SNOUT_EINVAL;
+    *out = nullptr;
+    if (cfg->abi_version != SNOUT_ABI_VERSION) {
+        set_last_error("abi_version %u != %u", cfg->abi_version, SNOUT_ABI_VERSION);
+        return SNOUT_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_last_error("no HIP device visible");
+        return SNOUT_ENODEV;
+    }
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return SNOUT_ENODEV; }
+    if (dev >= ndev) { set_last_error("device %d of %d", dev, ndev); return SNOUT_EINVAL; }
+    SNOUT_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    SNOUT_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error("device %d is %s; libsnout_rx is built for gfx950 only", dev, prop.gcnArchName);
+        return SNOUT_ENODEV;
+    }
+    snout_rx* h = new (std::nothrow) snout_rx();
+    if (!h) return SNOUT_ENOMEM;
+    h->cfg = *cfg;
+    h->device = dev;
+    snout_rx_cfg& c = h->cfg;
+    if (c.access_addr == 0) c.access_addr = 0x8E89BED6u;
+    if (c.crc_init == 0) c.crc_init = 0x555555u;
+    if (c.chip_threshold == 0) c.chip_threshold = 10;
+    if (c.taps_per_branch == 0) c.taps_per_branch = 16;
+    if (c.zb_core == 0) c.zb_core = 16384;
+    if (c.zb_warmup == 0) c.zb_warmup = 2048;
+    if (c.n_channels == 0) c.n_channels = 1;
+    int rc = SNOUT_EINVAL;
+    if (c.proto == SNOUT_PROTO_BTLE && c.n_channels == 1) {
+        if (c.channel > 39) { set_last_error("BTLE channel %u", c.channel); goto fail; }
+        uint16_t ch = (uint16_t)c.channel;
+        rc = h->btle.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
+        if (rc) goto fail;
+    } else {
+        set_last_error("configuration proto=%u n_channels=%u not supported", c.proto, c.n_channels);
+        goto fail;
+    }
+    *out = h;
+    return SNOUT_OK;
+fail:
+    h->btle.destroy();
+    delete h;
+    return rc;
+}
+
+void snout_rx_destroy(snout_rx* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->btle.destroy();
+    h->d_iq.release();
+    delete h;
+}
+
+int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
+                         uint64_t first_sample_index, void* hip_stream, snout_pkt* out, uint64_t cap,
+                         uint64_t* n_out)
+{
+    if (!h || !n_out || (!out && cap) || (!iq_dev && n_samples)) return SNOUT_EINVAL;
+    *n_out = 0;
+    h->have_prof = false;
+    if (n_samples >= 0xFFFF0000ull) { set_last_error("segment of %llu samples", (unsigned long long)n_samples); return SNOUT_ERANGE; }
+    if (n_samples < 5) return SNOUT_OK;
+    SNOUT_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (h->cfg.proto == SNOUT_PROTO_BTLE && h->cfg.n_channels == 1) {
+        BtleCtx& b = h->btle;
+        if (int rc = b.reserve(n_samples)) return rc;
+        SNOUT_HIP(hipEventRecord(b.ev_t0, st));
+        if (int rc = b.launch_demod_corr(iq_dev, n_samples, st)) return rc;
+        int rc = b.finish(n_samples, first_sample_index, st, out, cap, n_out);
+        h->last_n = n_samples;
+        h->last_pkts = *n_out;
+        h->have_prof = true;
+        return rc;
+    }
+    return SNOUT_EINVAL;
+}
+
+int snout_rx_process(snout_rx* h, const float* iq_host, uint64_t n_samples,
+                     uint64_t first_sample_index, snout_pkt* out, uint64_t cap, uint64_t* n_out)
+{
+    if (!h || !n_out || (!iq_host && n_samples)) return SNOUT_EINVAL;
+    *n_out = 0;
+    if (n_samples < 5) return SNOUT_OK;
+    SNOUT_HIP(hipSetDevice(h->device));
+    if (int rc = h->d_iq.ensure(n_samples * 8u)) return rc;
+    SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, n_samples * 8u, hipMemcpyHostToDevice));
+    return snout_rx_process_dev(h, h->d_iq.as<float>(), n_samples, first_sample_index, nullptr, out,
+                                cap, n_out);
+}
+
+int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
+{
+    if (!h || !out) return SNOUT_EINVAL;
+    memset(out, 0, sizeof(*out));
+    if (!h->have_prof) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
+    BtleCtx& b = h->btle;
+    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, b.ev_t0, b.ev_t1));
+    SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, b.ev_k0, b.ev_k1));
+    out->dominant_launches = 1;
+    out->n_hits = b.last_n_cand;
+    out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
+    snprintf(out->dominant_name, sizeof(out->dominant_name), "btle_demod_corr");
+    return SNOUT_OK;
+}
+
+int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out, uint64_t cap,
+                  uint64_t* n_out)
+{
+    if (!h || !n_out) return SNOUT_EINVAL;
+    *n_out = 0;
+    SNOUT_HIP(hipSetDevice(h->device));
+    if (stage == SNOUT_STAGE_BTLE_BITS && h->cfg.proto == SNOUT_PROTO_BTLE) {
+        BtleCtx& b = h->btle;
+        if (channel_slot >= b.n_slots || h->last_n < 5) return SNOUT_EINVAL;
+        const uint64_t nb = h->last_n - 4;
+        const uint64_t words = (uint64_t)b.n_chunks * kChunkIters * 4u;
+        std::vector<uint64_t> pl(words);
+        SNOUT_HIP(hipMemcpy(pl.data(), b.d_planes.as<uint64_t>() + channel_slot * b.plane_stride,
+                            words * 8u, hipMemcpyDeviceToHost));
+        *n_out = nb;
+        const uint64_t m = nb < cap ? nb : cap;
+        for (uint64_t n = 0; n < m; n++) {
+            const uint64_t g = n >> 8, l = (n & 255u) >> 2, j = n & 3u;
+            out[n] = (float)((pl[g * 4u + j] >> l) & 1ull);
+        }
+        return nb > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
+    }
+    set_last_error("stage %u not available for this configuration", stage);
+    return SNOUT_EINVAL;
+}
+
+}  // extern "C"

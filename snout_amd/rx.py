@@ -1,0 +1,134 @@
+"""Receiver handle: the Python face of the C ABI (one handle = one configured receive path)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PKT_DTYPE, PROTO_BTLE, PROTO_ZIGBEE, SnoutError  # noqa: F401
+
+
+@dataclass
+class Profile:
+    ms_total: float
+    ms_dominant: float
+    dominant_launches: int
+    n_hits: int
+    bytes_algorithmic: int
+    dominant_name: str
+
+
+class SnoutRx:
+    """``SnoutRx(proto, channel=37)`` -> ``process(iq)`` returns a numpy record array
+    (dtype :data:`PKT_DTYPE`). ``iq`` may be a numpy complex64/float32 array (host path,
+    PCIe-inclusive) or a torch CUDA tensor / (device pointer, n) pair (HBM-resident path)."""
+
+    def __init__(self, proto: int = PROTO_BTLE, channel: int = 37, n_channels: int = 1,
+                 access_addr: int = 0, crc_init: int = 0, chip_threshold: int = 0,
+                 taps_per_branch: int = 0, zb_core: int = 0, zb_warmup: int = 0,
+                 max_hits: int = 0, device: int = -1):
+        self._lib = _ffi.load()
+        cfg = _ffi.RxCfg(abi_version=_ffi.ABI_VERSION, proto=proto, n_channels=n_channels,
+                         taps_per_branch=taps_per_branch, channel=channel,
+                         access_addr=access_addr, crc_init=crc_init,
+                         chip_threshold=chip_threshold, zb_core=zb_core, zb_warmup=zb_warmup,
+                         max_hits=max_hits, device=device)
+        self._h = C.c_void_p()
+        _ffi.check(self._lib.snout_rx_create(C.byref(cfg), C.byref(self._h)))
+        self.proto = proto
+        self.n_channels = n_channels
+        self._out = np.zeros(4096, dtype=PKT_DTYPE)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.snout_rx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ensure_out(self, cap: int):
+        if self._out.size < cap:
+            self._out = np.zeros(cap, dtype=PKT_DTYPE)
+
+    def _run(self, fn, *args, cap: int):
+        self._ensure_out(cap)
+        while True:
+            n_out = C.c_uint64(0)
+            rc = fn(*args, self._out.ctypes.data_as(C.c_void_p), self._out.size, C.byref(n_out))
+            if rc == -5 and n_out.value > self._out.size:      # output capacity: grow and retry
+                self._out = np.zeros(int(n_out.value) + 1024, dtype=PKT_DTYPE)
+                continue
+            _ffi.check(rc)
+            return self._out[:n_out.value].copy()
+
+    def process(self, iq, first_sample_index: int = 0, stream: Optional[int] = None) -> np.ndarray:
+        if isinstance(iq, np.ndarray):
+            a = np.ascontiguousarray(iq)
+            if a.dtype == np.complex64:
+                a = a.view(np.float32)
+            if a.dtype != np.float32:
+                raise TypeError("iq must be complex64 or interleaved float32")
+            n = a.size // 2
+            return self._run(lambda *r: self._lib.snout_rx_process(
+                self._h, a.ctypes.data_as(C.c_void_p), n, first_sample_index, *r),
+                cap=max(4096, n // 2048))
+        # torch tensor on the GPU (complex64 [n] or float32 [2n])
+        import torch
+        if not (isinstance(iq, torch.Tensor) and iq.is_cuda and iq.is_contiguous()):
+            raise TypeError("iq must be a numpy array or a contiguous torch CUDA tensor")
+        if iq.dtype == torch.complex64:
+            n = iq.numel()
+        elif iq.dtype == torch.float32:
+            n = iq.numel() // 2
+        else:
+            raise TypeError("iq tensor must be complex64 or float32")
+        st = stream if stream is not None else torch.cuda.current_stream(iq.device).cuda_stream
+        return self._run(lambda *r: self._lib.snout_rx_process_dev(
+            self._h, C.c_void_p(iq.data_ptr()), n, first_sample_index, C.c_void_p(st), *r),
+            cap=max(4096, n // 2048))
+
+    def soft(self, stage: int, channel_slot: int = 0, cap: int = 0) -> np.ndarray:
+        cap = cap or (1 << 24)
+        out = np.zeros(cap, dtype=np.float32)
+        n = C.c_uint64(0)
+        _ffi.check(self._lib.snout_rx_soft(self._h, stage, channel_slot,
+                                           out.ctypes.data_as(C.c_void_p), cap, C.byref(n)),
+                   allow_overflow=True)
+        return out[:min(int(n.value), cap)]
+
+    def profile(self) -> Profile:
+        p = _ffi.RxProf()
+        _ffi.check(self._lib.snout_rx_profile(self._h, C.byref(p)))
+        return Profile(p.ms_total, p.ms_dominant, p.dominant_launches, p.n_hits,
+                       p.bytes_algorithmic, p.dominant_name.decode())
+
+
+def btle_format_line(pkt: np.void, fs_hz: float = 4e6, t0_epoch: float = 0.0, number: int = 0,
+                     access_addr: int = 0x8E89BED6) -> bytes:
+    lib = _ffi.load()
+    rec = np.array([pkt], dtype=PKT_DTYPE)
+    buf = C.create_string_buffer(512)
+    n = lib.snout_btle_format_line(rec.ctypes.data_as(C.c_void_p), fs_hz, t0_epoch, number,
+                                   access_addr, buf, 512)
+    if n < 0:
+        _ffi.check(n)
+    return buf.raw[:n]
+
+
+def rftap_encap(pkt: np.void) -> bytes:
+    lib = _ffi.load()
+    rec = np.array([pkt], dtype=PKT_DTYPE)
+    buf = (C.c_uint8 * 256)()
+    n = lib.snout_rftap_encap(rec.ctypes.data_as(C.c_void_p), buf, 256)
+    if n < 0:
+        _ffi.check(n)
+    return bytes(buf[:n])
