@@ -118,6 +118,11 @@ int  snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
                           uint64_t first_sample_index, void* hip_stream,
                           snout_pkt* out, uint64_t cap, uint64_t* n_out);
 
+/* Page-locked host memory for `out`: records are then DMA'd straight into it (no staging copy).
+ * Any other host pointer works too, through an internal pinned staging buffer. */
+void* snout_host_alloc(size_t bytes);
+void  snout_host_free(void* p);
+
 /* Copy a soft intermediate of the LAST processed segment to host floats (tests only). */
 int  snout_rx_soft   (snout_rx* h, uint32_t stage, uint32_t channel_slot,
                       float* out, uint64_t cap, uint64_t* n_out);

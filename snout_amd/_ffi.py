@@ -20,7 +20,7 @@ STAGE_BTLE_BITS, STAGE_CHAN_IQ, STAGE_ZB_DISCRIM, STAGE_ZB_DCREMOVED, STAGE_ZB_C
 
 EXPORTS = [
     "snout_rx_create", "snout_rx_destroy", "snout_rx_process", "snout_rx_process_dev",
-    "snout_rx_soft", "snout_rx_profile", "snout_btle_format_line", "snout_rftap_encap",
+    "snout_host_alloc", "snout_host_free", "snout_rx_soft", "snout_rx_profile", "snout_btle_format_line", "snout_rftap_encap",
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
     "snout_strerror", "snout_last_error", "snout_abi_version",
 ]
@@ -78,6 +78,10 @@ def load() -> C.CDLL:
     lib.snout_rx_process.restype = C.c_int
     lib.snout_rx_process_dev.argtypes = [vp, vp, u64, u64, vp, vp, u64, C.POINTER(u64)]
     lib.snout_rx_process_dev.restype = C.c_int
+    lib.snout_host_alloc.argtypes = [C.c_size_t]
+    lib.snout_host_alloc.restype = vp
+    lib.snout_host_free.argtypes = [vp]
+    lib.snout_host_free.restype = None
     lib.snout_rx_soft.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u64, C.POINTER(u64)]
     lib.snout_rx_soft.restype = C.c_int
     lib.snout_rx_profile.argtypes = [vp, C.POINTER(RxProf)]

@@ -176,149 +176,221 @@ __global__ __launch_bounds__(256) void btle_corr_planes(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exclusive prefix sum of min(in[i], clamp) over n items, one workgroup.  total -> *total_out.
+// Block-level helpers (256 threads = 4 waves).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void scan_u32(const uint32_t* __restrict__ in,
-                                                 uint32_t* __restrict__ out,
-                                                 const uint32_t* __restrict__ n_ptr, uint32_t n_fixed,
-                                                 uint32_t clamp, uint32_t* __restrict__ total_out)
+constexpr uint32_t kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kScanItems;  // 1024
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, uint32_t lane)
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const uint32_t n = n_ptr ? *n_ptr : n_fixed;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(x, d);
+        if ((int)lane >= d) x += t;
+    }
+    return x;
+}
+
+// Exclusive scan of one value per thread across the block; returns the prefix, *total = block sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* lds4, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(x, lane);
     __syncthreads();
-    constexpr uint32_t kPer = 8;
-    for (uint32_t base = 0; base < n; base += 1024u * kPer) {
-        uint32_t v[kPer];
-        uint32_t s = 0;
-        const uint32_t i0 = base + tid * kPer;
+    if (lane == 63) lds4[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; k++) {
-            uint32_t x = (i0 + k < n) ? in[i0 + k] : 0u;
-            x = x < clamp ? x : clamp;
-            v[k] = s;
-            s += x;
-        }
-        // inclusive scan of s across the wave
-        uint32_t inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d);
-            if ((int)lane >= d) inc += t;
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        uint32_t wbase = 0;
-        for (uint32_t w = 0; w < wv; w++) wbase += wsum[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + wbase + inc - s;
-#pragma unroll
-        for (uint32_t k = 0; k < kPer; k++)
-            if (i0 + k < n) out[i0 + k] = excl + v[k];
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + wbase + inc;
-        __syncthreads();
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t s = lds4[w];
+        if (w < wv) base += s;
+        tot += s;
     }
-    if (tid == 0) *total_out = carry_s;
+    *total = tot;
+    return base + inc - x;
+}
+
+// Sum of sums[0..count) computed by the whole block (count <= a few thousand).
+__device__ __forceinline__ uint32_t block_sum_prefix(const uint32_t* __restrict__ sums,
+                                                     uint32_t count, uint32_t* lds4)
+{
+    uint32_t x = 0;
+    for (uint32_t i = threadIdx.x; i < count; i += kScanBlock) x += sums[i];
+    uint32_t tot;
+    (void)block_excl_scan(x, lds4, &tot);
+    return tot;
+}
+
+// Per-tile sums of min(in[i], clamp) and a per-tile "some value exceeded clamp" flag.  n comes
+// from device memory when n_ptr is set (the count of a previous stage).
+__global__ __launch_bounds__(256) void tile_reduce(const uint32_t* __restrict__ in,
+                                                   const uint32_t* __restrict__ n_ptr,
+                                                   uint32_t n_fixed, uint32_t n_limit, uint32_t clamp,
+                                                   uint32_t* __restrict__ tile_sums,
+                                                   uint32_t* __restrict__ tile_over)
+{
+    __shared__ uint32_t lds4[4];
+    uint32_t n = n_ptr ? *n_ptr : n_fixed;
+    n = n < n_limit ? n : n_limit;
+    const uint32_t i0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t s = 0, over = 0;
+    if (i0 < n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + i0);   // buffers are padded to a tile
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t k = 0; k < kScanItems; k++) {
+            if (i0 + k < n) {
+                over |= x[k] > clamp ? 1u : 0u;
+                s += x[k] < clamp ? x[k] : clamp;
+            }
+        }
+    }
+    uint32_t tot, tot_over;
+    (void)block_excl_scan(s, lds4, &tot);
+    (void)block_excl_scan(over, lds4, &tot_over);
+    if (threadIdx.x == 0) {
+        tile_sums[blockIdx.x] = tot;
+        if (tile_over) tile_over[blockIdx.x] = tot_over;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// a2: decode every candidate.  One thread per (slot, chunk) hit list.
+// Per-(slot,chunk) hit lists -> one globally sorted candidate array (tile sums from tile_reduce).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t plane_byte(const uint64_t* __restrict__ pl, uint32_t j,
-                                               uint64_t sym)
+__global__ __launch_bounds__(256) void btle_flatten(
+    const uint32_t* __restrict__ chunk_cnt, const uint32_t* __restrict__ chunk_hits, uint32_t cap,
+    uint32_t n_lists, uint32_t n_chunks, const uint32_t* __restrict__ tile_sums, uint32_t n_tiles,
+    const uint32_t* __restrict__ tile_over, uint32_t* __restrict__ hit_n,
+    uint16_t* __restrict__ hit_slot, uint32_t max_cand, uint32_t* __restrict__ totals)
 {
-    const uint64_t w = sym >> 6;
-    const uint32_t s = (uint32_t)(sym & 63u);
-    uint64_t v = pl[w * 4u + j] >> s;
-    if (s > 56u) v |= pl[(w + 1u) * 4u + j] << (64u - s);
-    return (uint32_t)(v & 0xFFu);
-}
-
-__device__ __forceinline__ uint32_t crc24_update(uint32_t r, uint32_t byte)
-{
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t t = (r >> 23) & 1u;
-        r = (r << 1) & 0xFFFFFFu;
-        if (t != ((byte >> k) & 1u)) r ^= 0x00065Bu;
+    __shared__ uint32_t lds4[4];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tile_base = block_sum_prefix(tile_sums, tile, lds4);
+    if (tile == 0) {
+        const uint32_t all = block_sum_prefix(tile_sums, n_tiles, lds4);
+        const uint32_t over = block_sum_prefix(tile_over, n_tiles, lds4);
+        if (threadIdx.x == 0) { totals[0] = all; totals[2] = over; }
     }
-    return r;
+    const uint32_t l0 = tile * kScanTile + threadIdx.x * kScanItems;
+    uint32_t cnt[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; k++) {
+        uint32_t c = (l0 + k < n_lists) ? chunk_cnt[l0 + k] : 0u;
+        cnt[k] = c < cap ? c : cap;
+        s += cnt[k];
+    }
+    uint32_t tot;
+    uint32_t off = tile_base + block_excl_scan(s, lds4, &tot);
+    if (s == 0) return;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; k++) {
+        const uint32_t list = l0 + k;
+        for (uint32_t i = 0; i < cnt[k]; i++) {
+            if (off < max_cand) {
+                hit_n[off] = chunk_hits[(size_t)list * cap + i];
+                hit_slot[off] = (uint16_t)(list / n_chunks);
+            }
+            off++;
+        }
+    }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a2: decode every candidate, one thread each.  The packet is a contiguous run of <= 336 bits of
+// one phase plane: 7 words are fetched up front, aligned, XORed with the whitening sequence.
+// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void btle_decode(
     const uint64_t* __restrict__ planes, uint64_t plane_stride, uint64_t nb,
-    const uint32_t* __restrict__ chunk_cnt, const uint32_t* __restrict__ chunk_off,
-    const uint32_t* __restrict__ chunk_hits, uint32_t cap, uint32_t n_chunks, uint32_t n_slots,
-    const uint8_t* __restrict__ whiten /* [n_slots][42] */,
+    const uint32_t* __restrict__ hit_n, const uint16_t* __restrict__ hit_slot,
+    const uint32_t* __restrict__ totals, uint32_t max_cand,
+    const uint64_t* __restrict__ whiten /* [n_slots][6] u64 words */,
     const uint16_t* __restrict__ slot_channel, uint32_t crc_init, uint64_t first_index,
-    BtleCand* __restrict__ cand, snout_pkt* __restrict__ stage, uint32_t max_cand)
+    BtleCand* __restrict__ cand, snout_pkt* __restrict__ stage)
 {
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_chunks * n_slots;
-         t += gridDim.x * blockDim.x) {
-    uint32_t cnt = chunk_cnt[t];
-    cnt = cnt < cap ? cnt : cap;
-    if (cnt == 0) continue;
-    const uint32_t slot = t / n_chunks;
-    const uint64_t* pl = planes + (size_t)slot * plane_stride;
-    const uint8_t* wh = whiten + slot * 42u;
-    const uint32_t off = chunk_off[t];
-    for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t idx = off + k;
-        if (idx >= max_cand) break;
-        const uint32_t n_hit = chunk_hits[(size_t)t * cap + k];
+    __shared__ uint32_t crc_tab[256];      // reflected CRC24 table (poly 0x00065B reflected = 0xDA6000)
+    {
+        uint32_t c = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? ((c >> 1) ^ 0xDA6000u) : (c >> 1);
+        crc_tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    uint32_t n = totals[0];
+    n = n < max_cand ? n : max_cand;
+    const uint32_t crc0 = __brev(crc_init & 0xFFFFFFu) >> 8;     // register in reflected form
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += gridDim.x * blockDim.x) {
+        const uint32_t n_hit = hit_n[idx];
+        const uint32_t slot = hit_slot[idx];
+        const uint64_t* pl = planes + (size_t)slot * plane_stride;
         const uint32_t j = n_hit & 3u;
-        const uint64_t sym = (uint64_t)(n_hit >> 2) + 1u;   // first header symbol, phase j
+        const uint64_t sym = (uint64_t)(n_hit >> 2) + 1u;     // first header symbol of phase j
         const uint64_t hdr = (uint64_t)n_hit + 4u;
+        const uint64_t w0 = sym >> 6;
+        const uint32_t sh = (uint32_t)(sym & 63u);
+        uint64_t w[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) w[k] = pl[(w0 + k) * 4u + j];   // plane has a chunk of padding
+        uint64_t p[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint64_t al = sh ? ((w[k] >> sh) | (w[k + 1] << (64u - sh))) : w[k];
+            p[k] = al ^ whiten[slot * 6u + k];
+        }
         BtleCand c;
         c.n_hit = n_hit;
         c.slot = (uint16_t)slot;
         c.accept = 0;
-        snout_pkt* p = &stage[idx];
         if (!(hdr + 60u < nb)) {
             c.status = 1;
             c.next = n_hit + 1u;
         } else {
-            const uint32_t b0 = plane_byte(pl, j, sym) ^ wh[0];
-            const uint32_t b1 = plane_byte(pl, j, sym + 8u) ^ wh[1];
+            const uint32_t b0 = (uint32_t)(p[0] & 0xFFu), b1 = (uint32_t)((p[0] >> 8) & 0xFFu);
             const uint32_t plen = b1 & 0x3Fu;
             c.next = (uint32_t)(hdr + 64u);
-            if (plen < 6u || plen > 37u) {
-                c.status = 2;
-            } else {
+            c.status = 2;
+            if (plen >= 6u && plen <= 37u) {
                 const uint32_t total = plen + 5u;
-                if (!(hdr + 4u * (8u * (uint64_t)total - 1u) < nb)) {
-                    c.status = 3;
-                } else {
-                    uint32_t crc = crc24_update(crc24_update(crc_init & 0xFFFFFFu, b0), b1);
-                    p->bytes[0] = (uint8_t)b0;
-                    p->bytes[1] = (uint8_t)b1;
-                    uint32_t rx_crc = 0;    // received CRC bits in register order
-                    for (uint32_t b = 2; b < total; b++) {
-                        const uint32_t v = plane_byte(pl, j, sym + 8u * b) ^ wh[b];
-                        p->bytes[b] = (uint8_t)v;
-                        if (b < total - 3u) crc = crc24_update(crc, v);
-                        else rx_crc = (rx_crc << 8) | (__brev(v) >> 24);
+                c.status = 3;
+                if (hdr + 4u * (8u * (uint64_t)total - 1u) < nb) {
+                    // CRC over header+payload, then compare with the 3 received bytes
+                    uint32_t crc = crc0, rx = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+#pragma unroll
+                        for (int t = 0; t < 8; t++) {
+                            const uint32_t b = 8u * k + t;
+                            const uint32_t v = (uint32_t)(p[k] >> (8 * t)) & 0xFFu;
+                            if (b < plen + 2u) crc = (crc >> 8) ^ crc_tab[(crc ^ v) & 0xFFu];
+                            else if (b < total) rx |= v << (8u * (b - plen - 2u));
+                        }
                     }
-                    for (uint32_t b = total; b < 136u; b++) p->bytes[b] = 0;
-                    p->sample_index = first_index + (uint64_t)(n_hit - 124u);
-                    p->proto = SNOUT_PROTO_BTLE;
-                    p->channel = slot_channel[slot];
-                    p->len = (uint16_t)total;
-                    p->crc_ok = (uint8_t)(rx_crc == crc);
-                    p->lqi = 0;
-                    p->pdu_type = (uint8_t)(b0 & 0x0Fu);
-                    p->flags = (uint8_t)(((b0 >> 6) & 1u) | (((b0 >> 7) & 1u) << 1));
-                    p->aux = j;
+                    // zero everything past the packet and write the 160-byte record
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const int32_t keep = (int32_t)total - 8 * k;     // bytes of word k in use
+                        p[k] = keep >= 8 ? p[k] : (keep <= 0 ? 0ull : (p[k] & ((1ull << (8 * keep)) - 1ull)));
+                    }
+                    snout_pkt* o = &stage[idx];
+                    uint4* o4 = reinterpret_cast<uint4*>(o);
+                    const uint64_t si = first_index + (uint64_t)(n_hit - 124u);
+                    const uint32_t ok = (rx == crc) ? 1u : 0u;
+                    const uint32_t fl = ((b0 >> 6) & 1u) | (((b0 >> 7) & 1u) << 1);
+                    o4[0] = make_uint4((uint32_t)si, (uint32_t)(si >> 32), SNOUT_PROTO_BTLE,
+                                       (uint32_t)slot_channel[slot] | (total << 16));
+                    o4[1] = make_uint4(ok | ((b0 & 0x0Fu) << 16) | (fl << 24), j,
+                                       (uint32_t)p[0], (uint32_t)(p[0] >> 32));
+                    o4[2] = make_uint4((uint32_t)p[1], (uint32_t)(p[1] >> 32), (uint32_t)p[2], (uint32_t)(p[2] >> 32));
+                    o4[3] = make_uint4((uint32_t)p[3], (uint32_t)(p[3] >> 32), (uint32_t)p[4], (uint32_t)(p[4] >> 32));
+                    o4[4] = make_uint4((uint32_t)p[5], (uint32_t)(p[5] >> 32), 0u, 0u);
+#pragma unroll
+                    for (int q = 5; q < 10; q++) o4[q] = make_uint4(0u, 0u, 0u, 0u);
                     c.status = 0;
                     c.next = (uint32_t)(hdr + 32u * total);
                 }
             }
         }
         cand[idx] = c;
-    }
     }
 }
 
@@ -328,58 +400,80 @@ __global__ __launch_bounds__(256) void btle_decode(
 // point.  Candidates further apart than the longest packet cannot influence each other, so the
 // sorted list splits into independent clusters; each cluster head walks its own cluster.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void btle_resolve(BtleCand* __restrict__ cand,
-                                                    const uint32_t* __restrict__ n_cand_ptr,
+__global__ __launch_bounds__(256) void btle_resolve(const BtleCand* __restrict__ cand,
+                                                    const uint32_t* __restrict__ totals,
                                                     uint32_t max_cand,
                                                     uint32_t* __restrict__ accept_flag)
 {
-    uint32_t n = *n_cand_ptr;
+    uint32_t n = totals[0];
     n = n < max_cand ? n : max_cand;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const BtleCand me = cand[i];
-    bool head = (i == 0);
-    if (!head) {
-        const BtleCand pv = cand[i - 1];
-        head = pv.slot != me.slot || (me.n_hit - pv.n_hit) >= (uint32_t)kBtleMaxSpan;
-    }
-    if (!head) continue;
-    uint64_t resume = 0;
-    uint32_t k = i;
-    BtleCand c = me;
-    uint32_t last_n = me.n_hit;
-    while (true) {
-        uint32_t acc = 0;
-        if ((uint64_t)c.n_hit >= resume + 124u) {      // examined by the sequential search
-            acc = c.status == 0 ? 1u : 0u;
-            resume = c.next;
+        const BtleCand me = cand[i];
+        bool head = (i == 0);
+        if (!head) {
+            const BtleCand pv = cand[i - 1];
+            head = pv.slot != me.slot || (me.n_hit - pv.n_hit) >= (uint32_t)kBtleMaxSpan;
         }
-        accept_flag[k] = acc;
-        k++;
-        if (k >= n) break;
-        c = cand[k];
-        if (c.slot != me.slot || (c.n_hit - last_n) >= (uint32_t)kBtleMaxSpan) break;
-        last_n = c.n_hit;
-    }
+        if (!head) continue;
+        uint64_t resume = 0;
+        uint32_t k = i;
+        BtleCand c = me;
+        uint32_t last_n = me.n_hit;
+        while (true) {
+            uint32_t acc = 0;
+            if ((uint64_t)c.n_hit >= resume + 124u) {      // examined by the sequential search
+                acc = c.status == 0 ? 1u : 0u;
+                resume = c.next;
+            }
+            accept_flag[k] = acc;
+            k++;
+            if (k >= n) break;
+            c = cand[k];
+            if (c.slot != me.slot || (c.n_hit - last_n) >= (uint32_t)kBtleMaxSpan) break;
+            last_n = c.n_hit;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void emit_packets(const snout_pkt* __restrict__ stage,
-                                                    const uint32_t* __restrict__ accept_flag,
-                                                    const uint32_t* __restrict__ out_off,
-                                                    const uint32_t* __restrict__ n_cand_ptr,
-                                                    uint32_t max_cand, snout_pkt* __restrict__ out,
-                                                    uint32_t out_cap)
+// Ordered compaction of the accepted records (tile sums from tile_reduce over accept flags).
+__global__ __launch_bounds__(256) void btle_emit(const snout_pkt* __restrict__ stage,
+                                                 const uint32_t* __restrict__ accept_flag,
+                                                 const uint32_t* __restrict__ tile_sums,
+                                                 uint32_t* __restrict__ totals, uint32_t max_cand,
+                                                 snout_pkt* __restrict__ out, uint32_t out_cap)
 {
-    uint32_t n = *n_cand_ptr;
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t src_of[kScanTile];     // tile-local compact list: source candidate index
+    uint32_t n = totals[0];
     n = n < max_cand ? n : max_cand;
-    // 10 threads move one 160-byte record as 16-byte pieces
-    for (uint64_t g = blockIdx.x * blockDim.x + threadIdx.x; g < (uint64_t)n * 10u;
-         g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t i = (uint32_t)(g / 10u), piece = (uint32_t)(g % 10u);
-        if (!accept_flag[i]) continue;
-        const uint32_t o = out_off[i];
-        if (o >= out_cap) continue;
-        reinterpret_cast<uint4*>(&out[o])[piece] = reinterpret_cast<const uint4*>(&stage[i])[piece];
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    const uint32_t tile = blockIdx.x;
+    if (tile == 0) {
+        const uint32_t all = block_sum_prefix(tile_sums, n_tiles, lds4);
+        if (threadIdx.x == 0) totals[1] = all;
+    }
+    if (tile >= n_tiles) return;
+    const uint32_t tile_base = block_sum_prefix(tile_sums, tile, lds4);
+    const uint32_t i0 = tile * kScanTile + threadIdx.x * kScanItems;
+    uint32_t fl[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; k++) {
+        fl[k] = (i0 + k < n) ? accept_flag[i0 + k] : 0u;
+        s += fl[k];
+    }
+    uint32_t tot;
+    uint32_t off = block_excl_scan(s, lds4, &tot);
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; k++)
+        if (fl[k]) src_of[off++] = i0 + k;
+    __syncthreads();
+    // all threads move 16-byte pieces: record r of the tile, piece q
+    for (uint32_t g = threadIdx.x; g < tot * 10u; g += kScanBlock) {
+        const uint32_t r = g / 10u, q = g % 10u;
+        const uint32_t o = tile_base + r;
+        if (o < out_cap)
+            reinterpret_cast<uint4*>(&out[o])[q] = reinterpret_cast<const uint4*>(&stage[src_of[r]])[q];
     }
 }
 
@@ -392,6 +486,13 @@ namespace snout {
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_, uint32_t crc_init_,
                   uint32_t max_hits_)
 {
@@ -399,28 +500,25 @@ int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_
     aa = aa_;
     crc_init = crc_init_;
     max_hits_cfg = max_hits_;
-    // whitening sequences (LFSR x^7+x^4+1, position 0 = 1, positions 1..6 = channel MSB..LSB)
-    std::vector<uint8_t> wh(42u * n_slots);
+    // whitening sequences (LFSR x^7+x^4+1, position 0 = 1, positions 1..6 = channel MSB..LSB),
+    // 48 bytes per slot packed LSB-first into six u64 words
+    std::vector<uint64_t> wh(6u * n_slots, 0ull);
     std::vector<uint16_t> ch(n_slots);
     for (uint32_t s = 0; s < n_slots; s++) {
         ch[s] = slot_channel_[s];
         uint32_t reg = 1u;                                  // bit i = position i
         for (int i = 0; i < 6; i++) reg |= ((ch[s] >> (5 - i)) & 1u) << (1 + i);
-        for (int b = 0; b < 42; b++) {
-            uint8_t v = 0;
-            for (int k = 0; k < 8; k++) {
-                const uint32_t o = (reg >> 6) & 1u;
-                v |= (uint8_t)(o << k);
-                reg = ((reg << 1) & 0x7Fu) | o;             // shift, feed back into position 0
-                reg ^= o << 4;                              // and into position 4
-            }
-            wh[s * 42u + b] = v;
+        for (int b = 0; b < 384; b++) {
+            const uint32_t o = (reg >> 6) & 1u;
+            wh[s * 6u + (b >> 6)] |= (uint64_t)o << (b & 63);
+            reg = ((reg << 1) & 0x7Fu) | o;                 // shift, feed back into position 0
+            reg ^= o << 4;                                  // and into position 4
         }
     }
-    if (int rc = d_whiten.ensure(wh.size())) return rc;
+    if (int rc = d_whiten.ensure(wh.size() * 8)) return rc;
     if (int rc = d_slot_channel.ensure(ch.size() * 2)) return rc;
-    if (int rc = d_totals.ensure(64)) return rc;
-    SNOUT_HIP(hipMemcpy(d_whiten.p, wh.data(), wh.size(), hipMemcpyHostToDevice));
+    if (int rc = d_totals.ensure(kTotalsBytes)) return rc;
+    SNOUT_HIP(hipMemcpy(d_whiten.p, wh.data(), wh.size() * 8, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_slot_channel.p, ch.data(), ch.size() * 2, hipMemcpyHostToDevice));
     SNOUT_HIP(hipHostMalloc((void**)&h_totals, 64, hipHostMallocDefault));
     SNOUT_HIP(hipEventCreate(&ev_t0));
@@ -432,8 +530,8 @@ int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_
 
 void BtleCtx::destroy()
 {
-    d_planes.release(); d_chunk_cnt.release(); d_chunk_off.release(); d_chunk_hits.release();
-    d_cand.release(); d_stage.release(); d_accept.release(); d_out_off.release(); d_out.release();
+    d_planes.release(); d_chunk_cnt.release(); d_chunk_hits.release(); d_hit_n.release();
+    d_hit_slot.release(); d_cand.release(); d_stage.release(); d_accept.release(); d_out.release();
     d_whiten.release(); d_slot_channel.release(); d_totals.release();
     if (h_totals) (void)hipHostFree(h_totals);
     if (h_out) (void)hipHostFree(h_out);
@@ -448,16 +546,29 @@ int BtleCtx::reserve(uint64_t n)
     n_chunks = cdiv(n, kChunkSamples);
     plane_stride = (uint64_t)(n_chunks + 1) * kChunkIters * 4u;     // u64 words per slot (+1 chunk pad)
     const uint64_t lists = (uint64_t)n_chunks * n_slots;
-    max_cand = max_hits_cfg ? max_hits_cfg : (uint32_t)std::min<uint64_t>(n * n_slots / 1024u + 4096u, 1u << 26);
+    const uint32_t auto_cand = (uint32_t)std::min<uint64_t>(n * n_slots / 1024u + 4096u, 1u << 26);
+    max_cand = std::max(max_cand_grown, max_hits_cfg ? max_hits_cfg : auto_cand);
+    if (cdiv(lists, kScanTile) > kMaxTiles || cdiv(max_cand, kScanTile) > kMaxTiles) {
+        set_last_error("segment too large for the tile-sum tables");
+        return SNOUT_ERANGE;
+    }
     if (int rc = d_planes.ensure(plane_stride * n_slots * 8u)) return rc;
-    if (int rc = d_chunk_cnt.ensure(lists * 4u)) return rc;
-    if (int rc = d_chunk_off.ensure(lists * 4u)) return rc;
-    if (int rc = d_chunk_hits.ensure(lists * kChunkHitCap * 4u)) return rc;
+    if (int rc = d_chunk_cnt.ensure((lists + kScanTile) * 4u)) return rc;
+    if (int rc = d_chunk_hits.ensure(lists * hit_cap * 4u)) return rc;
+    if (int rc = d_hit_n.ensure((uint64_t)max_cand * 4u)) return rc;
+    if (int rc = d_hit_slot.ensure((uint64_t)max_cand * 2u)) return rc;
     if (int rc = d_cand.ensure((uint64_t)max_cand * sizeof(BtleCand))) return rc;
     if (int rc = d_stage.ensure((uint64_t)max_cand * sizeof(snout_pkt))) return rc;
-    if (int rc = d_accept.ensure((uint64_t)max_cand * 4u)) return rc;
-    if (int rc = d_out_off.ensure((uint64_t)max_cand * 4u)) return rc;
+    if (int rc = d_accept.ensure(((uint64_t)max_cand + kScanTile) * 4u)) return rc;
     if (int rc = d_out.ensure((uint64_t)max_cand * sizeof(snout_pkt))) return rc;
+    return 0;
+}
+
+// totals layout (u32): [0] n_cand  [1] n_out  [2] raw hit count  [16..16+kMaxTiles) list tile sums
+//                      [16+kMaxTiles ..) accept tile sums
+int BtleCtx::begin(hipStream_t st)
+{
+    SNOUT_HIP(hipEventRecord(ev_t0, st));
     return 0;
 }
 
@@ -467,7 +578,7 @@ int BtleCtx::launch_demod_corr(const float* d_iq, uint64_t n, hipStream_t st)
     SNOUT_HIP(hipEventRecord(ev_k0, st));
     hipLaunchKernelGGL(btle_demod_corr, dim3(cdiv(n_chunks, 4)), dim3(256), 0, st, d_iq, n, aa,
                        n_chunks, d_planes.as<uint64_t>(), d_chunk_cnt.as<uint32_t>(),
-                       d_chunk_hits.as<uint32_t>(), (uint32_t)kChunkHitCap);
+                       d_chunk_hits.as<uint32_t>(), hit_cap);
     SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());
     return 0;
@@ -478,7 +589,7 @@ int BtleCtx::launch_corr_planes(uint64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(btle_corr_planes, dim3(cdiv((uint64_t)n_chunks * n_slots, 4)), dim3(256), 0, st,
                        d_planes.as<uint64_t>(), plane_stride, n - 4u, aa, n_chunks, n_slots,
-                       d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), (uint32_t)kChunkHitCap);
+                       d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap);
     SNOUT_HIP(hipGetLastError());
     return 0;
 }
@@ -488,25 +599,28 @@ int BtleCtx::finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt*
                     uint64_t* n_out)
 {
     const uint32_t lists = n_chunks * n_slots;
-    uint32_t* tot = d_totals.as<uint32_t>();     // [0]=n_cand [1]=n_out [2]=sum of raw counts
-    hipLaunchKernelGGL(scan_u32, dim3(1), dim3(1024), 0, st, d_chunk_cnt.as<uint32_t>(),
-                       d_chunk_off.as<uint32_t>(), (const uint32_t*)nullptr, lists,
-                       (uint32_t)kChunkHitCap, tot + 0);
-    hipLaunchKernelGGL(scan_u32, dim3(1), dim3(1024), 0, st, d_chunk_cnt.as<uint32_t>(),
-                       d_out_off.as<uint32_t>() /*scratch*/, (const uint32_t*)nullptr, lists,
-                       0xFFFFFFFFu, tot + 2);
-    const uint32_t g = std::min<uint32_t>(cdiv(lists, 256), 2048u);
+    uint32_t* tot = d_totals.as<uint32_t>();
+    uint32_t* list_tiles = tot + 16;
+    uint32_t* acc_tiles = tot + 16 + kMaxTiles;
+    uint32_t* over_tiles = tot + 16 + 2 * kMaxTiles;
+    const uint32_t n_list_tiles = cdiv(lists, kScanTile);
+    const uint32_t n_cand_tiles = cdiv(max_cand, kScanTile);
+    hipLaunchKernelGGL(tile_reduce, dim3(n_list_tiles), dim3(256), 0, st, d_chunk_cnt.as<uint32_t>(),
+                       (const uint32_t*)nullptr, lists, lists, hit_cap, list_tiles, over_tiles);
+    hipLaunchKernelGGL(btle_flatten, dim3(n_list_tiles), dim3(256), 0, st, d_chunk_cnt.as<uint32_t>(),
+                       d_chunk_hits.as<uint32_t>(), hit_cap, lists, n_chunks, list_tiles, n_list_tiles,
+                       over_tiles, d_hit_n.as<uint32_t>(), d_hit_slot.as<uint16_t>(), max_cand, tot);
+    const uint32_t g = std::min<uint32_t>(cdiv(max_cand, 256), 1024u);
     hipLaunchKernelGGL(btle_decode, dim3(g), dim3(256), 0, st, d_planes.as<uint64_t>(), plane_stride,
-                       n - 4u, d_chunk_cnt.as<uint32_t>(), d_chunk_off.as<uint32_t>(),
-                       d_chunk_hits.as<uint32_t>(), (uint32_t)kChunkHitCap, n_chunks, n_slots,
-                       d_whiten.as<uint8_t>(), d_slot_channel.as<uint16_t>(), crc_init, first_index,
-                       d_cand.as<BtleCand>(), d_stage.as<snout_pkt>(), max_cand);
-    hipLaunchKernelGGL(btle_resolve, dim3(1024), dim3(256), 0, st, d_cand.as<BtleCand>(), tot + 0,
-                       max_cand, d_accept.as<uint32_t>());
-    hipLaunchKernelGGL(scan_u32, dim3(1), dim3(1024), 0, st, d_accept.as<uint32_t>(),
-                       d_out_off.as<uint32_t>(), tot + 0, 0u, 1u, tot + 1);
-    hipLaunchKernelGGL(emit_packets, dim3(1024), dim3(256), 0, st, d_stage.as<snout_pkt>(),
-                       d_accept.as<uint32_t>(), d_out_off.as<uint32_t>(), tot + 0, max_cand,
+                       n - 4u, d_hit_n.as<uint32_t>(), d_hit_slot.as<uint16_t>(), tot, max_cand,
+                       d_whiten.as<uint64_t>(), d_slot_channel.as<uint16_t>(), crc_init, first_index,
+                       d_cand.as<BtleCand>(), d_stage.as<snout_pkt>());
+    hipLaunchKernelGGL(btle_resolve, dim3(g), dim3(256), 0, st, d_cand.as<BtleCand>(), tot, max_cand,
+                       d_accept.as<uint32_t>());
+    hipLaunchKernelGGL(tile_reduce, dim3(n_cand_tiles), dim3(256), 0, st, d_accept.as<uint32_t>(),
+                       tot, 0u, max_cand, 1u, acc_tiles, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(btle_emit, dim3(n_cand_tiles), dim3(256), 0, st,
+                       d_stage.as<snout_pkt>(), d_accept.as<uint32_t>(), acc_tiles, tot, max_cand,
                        d_out.as<snout_pkt>(), max_cand);
     SNOUT_HIP(hipGetLastError());
     SNOUT_HIP(hipMemcpyAsync(h_totals, tot, 16, hipMemcpyDeviceToHost, st));
@@ -516,14 +630,24 @@ int BtleCtx::finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt*
     uint64_t np = h_totals[1];
     *n_out = np;
     int rc = 0;
-    if (raw > h_totals[0] || h_totals[0] > max_cand) {
-        set_last_error("BTLE hit capacity exceeded: %u raw hits, per-chunk cap %d, max_cand %u",
-                       raw, kChunkHitCap, max_cand);
-        rc = SNOUT_EOVERFLOW;
+    overflow_chunk = raw != 0;      // some chunk list was longer than hit_cap
+    overflow_cand = h_totals[0] > max_cand;
+    if (overflow_chunk || overflow_cand) {
+        // the caller (snout_rx_process_dev) grows the capacity and runs the segment again
+        set_last_error("BTLE hit capacity exceeded: %u candidates, per-chunk cap %u, max_cand %u",
+                       h_totals[0], hit_cap, max_cand);
+        *n_out = 0;
+        SNOUT_HIP(hipEventRecord(ev_t1, st));
+        return SNOUT_EOVERFLOW;
     }
-    if (np > cap) { np = cap; if (!rc) { set_last_error("output capacity %llu < %u packets",
-                                         (unsigned long long)cap, h_totals[1]); rc = SNOUT_EOVERFLOW; } }
-    if (np) {
+    if (np > cap) { np = cap; set_last_error("output capacity %llu < %u packets",
+                                             (unsigned long long)cap, h_totals[1]); rc = SNOUT_EOVERFLOW; }
+    if (np && host_is_pinned(out)) {
+        // caller's buffer is pinned (snout_host_alloc): DMA straight into it
+        SNOUT_HIP(hipMemcpyAsync(out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
+        SNOUT_HIP(hipEventRecord(ev_t1, st));
+        SNOUT_HIP(hipStreamSynchronize(st));
+    } else if (np) {
         // staged through pinned memory so the copy runs at full PCIe rate whatever `out` is
         if (h_out_cap < np) {
             if (h_out) (void)hipHostFree(h_out);

@@ -28,6 +28,8 @@ constexpr int kWave = 64;
 constexpr int kIterSamples = 256;   // samples one wave consumes per iteration (4 per lane)
 constexpr int kChunkIters = 64;     // iterations per chunk -> 16384 samples per wave
 constexpr int kChunkSamples = kIterSamples * kChunkIters;
+constexpr uint32_t kMaxTiles = 65536;                     // tile-sum table entries (1024 items each)
+constexpr size_t kTotalsBytes = (16 + 3 * kMaxTiles) * 4;
 constexpr int kBtleMaxSpan = 128 + 32 * (2 + 37 + 3);   // AA start -> end of CRC, samples
 
 // Candidate produced by the decode kernel, consumed by resolve/emit.
@@ -40,6 +42,8 @@ struct BtleCand {
 };
 static_assert(sizeof(BtleCand) == 12, "BtleCand layout");
 
+bool host_is_pinned(const void* p);
+
 // A growable device buffer.
 struct DevBuf {
     void*  p = nullptr;
@@ -50,14 +54,15 @@ struct DevBuf {
 };
 
 
-constexpr int kChunkHitCap = 32;    // candidate hits one 16384-sample chunk can hold
 
 // BTLE pipeline state shared by the narrowband and the channelized front ends (btle.hip).
 struct BtleCtx {
-    uint32_t n_slots = 0, aa = 0, crc_init = 0, max_hits_cfg = 0;
+    uint32_t n_slots = 0, aa = 0, crc_init = 0, max_hits_cfg = 0, max_cand_grown = 0;
     uint32_t n_chunks = 0, max_cand = 0, last_n_cand = 0;
+    uint32_t hit_cap = 64;          // candidate hits one 16384-sample chunk can hold (grows on overflow)
+    bool overflow_chunk = false, overflow_cand = false;
     uint64_t plane_stride = 0;
-    DevBuf d_planes, d_chunk_cnt, d_chunk_off, d_chunk_hits, d_cand, d_stage, d_accept, d_out_off,
+    DevBuf d_planes, d_chunk_cnt, d_chunk_hits, d_hit_n, d_hit_slot, d_cand, d_stage, d_accept,
         d_out, d_whiten, d_slot_channel, d_totals;
     uint32_t* h_totals = nullptr;
     snout_pkt* h_out = nullptr;
@@ -68,6 +73,7 @@ struct BtleCtx {
              uint32_t max_hits);
     void destroy();
     int reserve(uint64_t n_channel_samples);
+    int begin(hipStream_t st);
     int launch_demod_corr(const float* d_iq, uint64_t n, hipStream_t st);
     int launch_corr_planes(uint64_t n, hipStream_t st);
     int finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt* out, uint64_t cap,

@@ -150,10 +150,17 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
     hipStream_t st = (hipStream_t)hip_stream;
     if (h->cfg.proto == SNOUT_PROTO_BTLE && h->cfg.n_channels == 1) {
         BtleCtx& b = h->btle;
-        if (int rc = b.reserve(n_samples)) return rc;
-        SNOUT_HIP(hipEventRecord(b.ev_t0, st));
-        if (int rc = b.launch_demod_corr(iq_dev, n_samples, st)) return rc;
-        int rc = b.finish(n_samples, first_sample_index, st, out, cap, n_out);
+        int rc = 0;
+        for (int attempt = 0; attempt < 12; attempt++) {
+            if ((rc = b.reserve(n_samples))) return rc;
+            if ((rc = b.begin(st))) return rc;
+            if ((rc = b.launch_demod_corr(iq_dev, n_samples, st))) return rc;
+            rc = b.finish(n_samples, first_sample_index, st, out, cap, n_out);
+            if (rc != SNOUT_EOVERFLOW || !(b.overflow_chunk || b.overflow_cand)) break;
+            // more hits than provisioned: grow and run the segment again (results never truncated)
+            if (b.overflow_chunk) b.hit_cap = std::min<uint32_t>(b.hit_cap * 4u, kChunkSamples);
+            if (b.overflow_cand) b.max_cand_grown = b.max_cand * 4u;
+        }
         h->last_n = n_samples;
         h->last_pkts = *n_out;
         h->have_prof = true;
@@ -173,6 +180,22 @@ int snout_rx_process(snout_rx* h, const float* iq_host, uint64_t n_samples,
     SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, n_samples * 8u, hipMemcpyHostToDevice));
     return snout_rx_process_dev(h, h->d_iq.as<float>(), n_samples, first_sample_index, nullptr, out,
                                 cap, n_out);
+}
+
+void* snout_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        set_last_error("hipHostMalloc(%zu) failed", bytes);
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void snout_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int snout_rx_profile(snout_rx* h, snout_rx_prof* out)

@@ -40,12 +40,29 @@ class SnoutRx:
         _ffi.check(self._lib.snout_rx_create(C.byref(cfg), C.byref(self._h)))
         self.proto = proto
         self.n_channels = n_channels
-        self._out = np.zeros(4096, dtype=PKT_DTYPE)
+        self._out = None
+        self._out_ptr = None
+        self._alloc_out(4096)
+
+    def _alloc_out(self, cap: int):
+        """Records land in page-locked memory owned by this handle (DMA target, no staging)."""
+        if self._out_ptr:
+            self._out = None
+            self._lib.snout_host_free(self._out_ptr)
+        self._out_ptr = self._lib.snout_host_alloc(cap * PKT_DTYPE.itemsize)
+        if not self._out_ptr:
+            raise MemoryError("snout_host_alloc failed")
+        buf = (C.c_uint8 * (cap * PKT_DTYPE.itemsize)).from_address(self._out_ptr)
+        self._out = np.frombuffer(buf, dtype=PKT_DTYPE)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.snout_rx_destroy(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_out_ptr", None):
+            self._out = None
+            self._lib.snout_host_free(self._out_ptr)
+            self._out_ptr = None
 
     __del__ = close
 
@@ -55,22 +72,23 @@ class SnoutRx:
     def __exit__(self, *a):
         self.close()
 
-    def _ensure_out(self, cap: int):
+    def _run(self, fn, *args, cap: int, copy: bool = True):
         if self._out.size < cap:
-            self._out = np.zeros(cap, dtype=PKT_DTYPE)
-
-    def _run(self, fn, *args, cap: int):
-        self._ensure_out(cap)
+            self._alloc_out(cap)
         while True:
             n_out = C.c_uint64(0)
-            rc = fn(*args, self._out.ctypes.data_as(C.c_void_p), self._out.size, C.byref(n_out))
+            rc = fn(*args, C.c_void_p(self._out_ptr), self._out.size, C.byref(n_out))
             if rc == -5 and n_out.value > self._out.size:      # output capacity: grow and retry
-                self._out = np.zeros(int(n_out.value) + 1024, dtype=PKT_DTYPE)
+                self._alloc_out(int(n_out.value) + 1024)
                 continue
             _ffi.check(rc)
-            return self._out[:n_out.value].copy()
+            view = self._out[:n_out.value]
+            return view.copy() if copy else view
 
-    def process(self, iq, first_sample_index: int = 0, stream: Optional[int] = None) -> np.ndarray:
+    def process(self, iq, first_sample_index: int = 0, stream: Optional[int] = None,
+                copy: bool = True) -> np.ndarray:
+        """Run one capture segment. ``copy=False`` returns a view of the handle's pinned record
+        buffer, valid until the next call."""
         if isinstance(iq, np.ndarray):
             a = np.ascontiguousarray(iq)
             if a.dtype == np.complex64:
@@ -80,7 +98,7 @@ class SnoutRx:
             n = a.size // 2
             return self._run(lambda *r: self._lib.snout_rx_process(
                 self._h, a.ctypes.data_as(C.c_void_p), n, first_sample_index, *r),
-                cap=max(4096, n // 2048))
+                cap=max(4096, n // 2048), copy=copy)
         # torch tensor on the GPU (complex64 [n] or float32 [2n])
         import torch
         if not (isinstance(iq, torch.Tensor) and iq.is_cuda and iq.is_contiguous()):
@@ -94,7 +112,7 @@ class SnoutRx:
         st = stream if stream is not None else torch.cuda.current_stream(iq.device).cuda_stream
         return self._run(lambda *r: self._lib.snout_rx_process_dev(
             self._h, C.c_void_p(iq.data_ptr()), n, first_sample_index, C.c_void_p(st), *r),
-            cap=max(4096, n // 2048))
+            cap=max(4096, n // 2048), copy=copy)
 
     def soft(self, stage: int, channel_slot: int = 0, cap: int = 0) -> np.ndarray:
         cap = cap or (1 << 24)

@@ -1,7 +1,7 @@
 """Quick on-GPU timing of the BTLE path at a few sizes (developer tool)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snout_amd import synth
 from snout_amd.rx import SnoutRx
 
@@ -18,7 +18,7 @@ for rep in (1, 16, 64, 238):
         pk = rx.process(x)
     ts = []
     for _ in range(5):
-        t0 = time.perf_counter(); pk = rx.process(x); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); pk = rx.process(x, copy=False); ts.append(time.perf_counter() - t0)
     p = rx.profile()
     print(f"n={n:>11d} pkts={len(pk)} ok={int(pk['crc_ok'].sum())} expect={rep*len(truth)} "
           f"wall={min(ts)*1e3:.3f} ms dev_total={p.ms_total:.3f} k1={p.ms_dominant:.3f} ms "
