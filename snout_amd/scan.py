@@ -1,0 +1,215 @@
+"""Scan handlers: counterparts of snout/util/btle.py:22-122 (BtleScan) and the passive path of
+snout/util/zigbee.py:26-70,194-209 + snout/core/radio.py:399-443 (ZigbeeScan / Scan.run), with the
+external receivers (the ``btle_rx`` child, the GNU Radio flowgraph) replaced by libsnout_rx.so.
+
+The scan loop semantics are the reference's: channels are visited in order; each packet goes
+through ``handle_packet`` (which applies the same accept rule as BtleMessage.fromraw, appends to
+``packets``, writes the dump file and emits ``btle.packet-received``); ``check_stop`` ends a
+channel when ``packet_threshold`` packets were seen or ``timeout`` seconds elapsed.  With a
+recorded/synthetic capture "elapsed" is capture time (sample_index / fs), not wall-clock.
+"""
+from __future__ import annotations
+
+import socket
+import time
+from typing import Callable, Dict, Iterable, List, Optional
+
+import numpy as np
+
+from . import _ffi
+from .message import BtleMessage, ZigbeeMessage
+from .rx import SnoutRx, btle_format_line, rftap_encap
+
+BTLE_FS = 4e6
+ZIGBEE_FS = 4e6
+SEGMENT = 1 << 24           # samples per processing segment
+BTLE_OVERLAP = 1504         # longest BTLE packet, samples
+ZIGBEE_OVERLAP = 17024 + 2048
+
+
+class IqSource:
+    """Where a scan gets its samples: ``read(channel)`` -> complex64 array for that channel."""
+
+    def read(self, channel: int) -> np.ndarray:  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class FileSource(IqSource):
+    """cf32 file (GNU Radio file_sink format) holding one channel."""
+
+    def __init__(self, path: str):
+        self.path = path
+
+    def read(self, channel: int) -> np.ndarray:
+        return np.fromfile(self.path, dtype=np.complex64)
+
+
+class ArraySource(IqSource):
+    def __init__(self, arrays: Dict[int, np.ndarray]):
+        self.arrays = arrays
+
+    def read(self, channel: int) -> np.ndarray:
+        return self.arrays[channel]
+
+
+class _Events:
+    """Minimal event bus (reference: snout/core/__init__.py:18-58)."""
+
+    def __init__(self):
+        self._handlers: Dict[str, List[Callable]] = {}
+
+    def on(self, name: str, fn: Callable):
+        self._handlers.setdefault(name, []).append(fn)
+
+    def emit(self, name: str, **kw):
+        for fn in self._handlers.get(name, []):
+            fn(**kw)
+
+
+class BtleScan:
+    def __init__(self, channels: Iterable[int] = (37,), source: Optional[IqSource] = None,
+                 timeout: Optional[float] = 10.0, packet_threshold: Optional[int] = None,
+                 filename: Optional[str] = None, t0_epoch: Optional[float] = None,
+                 access_addr: int = 0x8E89BED6, crc_init: int = 0x555555, device: int = -1):
+        self.channels = list(channels)
+        self.source = source
+        self.timeout = timeout
+        self.packet_threshold = packet_threshold
+        self.filename = filename
+        self.save_file = open(filename, "wb") if filename else None
+        self.t0_epoch = time.time() if t0_epoch is None else t0_epoch
+        self.access_addr = access_addr
+        self.crc_init = crc_init
+        self.device = device
+        self.packets: List[BtleMessage] = []
+        self.events = _Events()
+        self._pkt_no = 0
+        self._elapsed = 0.0
+        self.start_time = None
+
+    # -- the replaced child process: one receiver handle per channel -------------------------
+    def lines(self, channel: int):
+        """Yield btle_rx-grammar lines (bytes) for every PDU found on `channel`, CRC0 and CRC1
+        alike, in capture order — what the reference reads from the child's stdout."""
+        x = self.source.read(channel)
+        with SnoutRx(proto=_ffi.PROTO_BTLE, channel=channel, access_addr=self.access_addr,
+                     crc_init=self.crc_init, device=self.device) as rx:
+            start = 0
+            seen_until = -1
+            while start < len(x):
+                stop = min(start + SEGMENT + BTLE_OVERLAP, len(x))
+                for p in rx.process(x[start:stop], first_sample_index=start):
+                    si = int(p["sample_index"])
+                    if si <= seen_until:         # found again in the overlap of the next segment
+                        continue
+                    seen_until = si
+                    self._elapsed = si / BTLE_FS
+                    yield btle_format_line(p, BTLE_FS, self.t0_epoch, self._pkt_no, self.access_addr)
+                    self._pkt_no += 1
+                start += SEGMENT
+
+    def run(self):
+        self.start_time = time.time()
+        for ch in self.channels:
+            self._elapsed = 0.0
+            n_before = len(self.packets)
+            for line in self.lines(ch):
+                self.handle_packet(line)
+                if self.check_stop(n_before):
+                    break
+        return self.conclude()
+
+    def handle_packet(self, line: bytes) -> bool:
+        message = BtleMessage.fromraw(line)
+        if not message:
+            return False
+        if self.save_file:
+            self.save_file.write(line)
+        self.packets.append(message)
+        self.events.emit("btle.packet-received", message=message)
+        return True
+
+    def check_stop(self, n_before: int = 0) -> bool:
+        if self.packet_threshold and len(self.packets) >= self.packet_threshold:
+            return True
+        if self.timeout and self._elapsed >= self.timeout:
+            return True
+        return False
+
+    def conclude(self):
+        if self.save_file:
+            self.save_file.close()
+            self.save_file = None
+        return self.packets
+
+
+class ZigbeeScan:
+    """Passive 802.15.4 scan. Each frame is turned into the datagram the reference's flowgraph
+    sends to UDP 127.0.0.1:52002 (RFtap header + MPDU); ``udp=True`` really sends it so an
+    unmodified scapy-radio ``GnuradioSocket`` sniff loop receives it."""
+
+    def __init__(self, channels: Iterable[int] = (11,), source: Optional[IqSource] = None,
+                 timeout: Optional[float] = 10.0, packet_threshold: Optional[int] = None,
+                 udp: bool = False, udp_addr=("127.0.0.1", 52002), t0_epoch: Optional[float] = None,
+                 device: int = -1):
+        self.channels = list(channels)
+        self.source = source
+        self.timeout = timeout
+        self.packet_threshold = packet_threshold
+        self.udp_addr = udp_addr
+        self.sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM) if udp else None
+        self.t0_epoch = time.time() if t0_epoch is None else t0_epoch
+        self.device = device
+        self.packets: List[ZigbeeMessage] = []
+        self.events = _Events()
+        self._elapsed = 0.0
+
+    def frames(self, channel: int):
+        x = self.source.read(channel)
+        with SnoutRx(proto=_ffi.PROTO_ZIGBEE, channel=channel, device=self.device) as rx:
+            start = 0
+            seen_until = -1
+            while start < len(x):
+                stop = min(start + SEGMENT + ZIGBEE_OVERLAP, len(x))
+                for p in rx.process(x[start:stop], first_sample_index=start):
+                    si = int(p["sample_index"])
+                    if si <= seen_until:
+                        continue
+                    seen_until = si
+                    self._elapsed = si / ZIGBEE_FS
+                    yield p
+                start += SEGMENT
+
+    def run(self):
+        for ch in self.channels:
+            self._elapsed = 0.0
+            for p in self.frames(ch):
+                self.handle_packet(p)
+                if self.check_stop():
+                    break
+        return self.conclude()
+
+    def handle_packet(self, p) -> bool:
+        dgram = rftap_encap(p)
+        if self.sock:
+            self.sock.sendto(dgram, self.udp_addr)
+        m = ZigbeeMessage(channel=int(p["channel"]), mpdu=bytes(p["bytes"][:p["len"]]),
+                          lqi=int(p["lqi"]), qual=int(p["lqi"]) / 255.0,
+                          timestamp=self.t0_epoch + int(p["sample_index"]) / ZIGBEE_FS,
+                          datagram=dgram)
+        self.packets.append(m)
+        self.events.emit("zigbee.packet-received", message=m)
+        return True
+
+    def check_stop(self) -> bool:
+        if self.packet_threshold and len(self.packets) >= self.packet_threshold:
+            return True
+        if self.timeout and self._elapsed >= self.timeout:
+            return True
+        return False
+
+    def conclude(self):
+        if self.sock:
+            self.sock.close()
+            self.sock = None
+        return self.packets

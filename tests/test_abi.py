@@ -1,0 +1,79 @@
+"""The drop-in boundary: libsnout_rx.so loads, exports every symbol include/snout_rx.h declares,
+struct layouts match, and (without a GPU) fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "snout_rx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(snout_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from snout_amd import _ffi
+    lib = _ffi.load()
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/snout_rx.h but not exported"
+    assert set(names) == set(_ffi.EXPORTS)
+
+
+def test_struct_layouts():
+    from snout_amd import _ffi
+    assert _ffi.PKT_DTYPE.itemsize == 160
+    assert _ffi.PKT_DTYPE.fields["bytes"][1] == 24
+    assert C.sizeof(_ffi.RxCfg) == 16 * 4
+    assert C.sizeof(_ffi.RxProf) == 24 + 48
+
+
+def test_strerror_and_channel_plans():
+    from snout_amd import _ffi
+    lib = _ffi.load()
+    assert lib.snout_strerror(0) == b"ok"
+    assert b"no CPU fallback" in lib.snout_strerror(-2)
+    # snout/modulations/Zigbee/hackrf/Zigbee_rx/top_block.py:56 : 1e6*(2400+5*(ch-10))
+    for ch in range(11, 27):
+        assert lib.snout_zigbee_center_hz(ch) == 1e6 * (2400 + 5 * (ch - 10))
+    assert lib.snout_btle_center_hz(37) == 2402e6
+    assert lib.snout_btle_center_hz(38) == 2426e6
+    assert lib.snout_btle_center_hz(39) == 2480e6
+    assert lib.snout_btle_center_hz(0) == 2404e6 and lib.snout_btle_center_hz(11) == 2428e6
+    rf = [lib.snout_btle_rf_to_channel(k) for k in range(40)]
+    assert sorted(rf) == list(range(40)) and rf[0] == 37 and rf[12] == 38 and rf[39] == 39
+    for k, ch in enumerate(rf):
+        assert lib.snout_btle_center_hz(ch) == (2402 + 2 * k) * 1e6
+    assert lib.snout_btle_rf_to_channel(40) == -1
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product must refuse to run (never route through the oracle)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from snout_amd._ffi import SnoutError
+    from snout_amd.rx import SnoutRx
+    with pytest.raises(SnoutError) as e:
+        SnoutRx(proto=0, channel=37)
+    assert e.value.code == -2
+
+
+def test_bad_arguments_are_rejected():
+    from snout_amd import _ffi
+    lib = _ffi.load()
+    h = C.c_void_p()
+    assert lib.snout_rx_create(None, C.byref(h)) == -1
+    cfg = _ffi.RxCfg(abi_version=99)
+    assert lib.snout_rx_create(C.byref(cfg), C.byref(h)) == -1
+    n = C.c_uint64()
+    assert lib.snout_rx_process(None, None, 0, 0, None, 0, C.byref(n)) == -1
+    rec = np.zeros(1, dtype=_ffi.PKT_DTYPE)
+    buf = C.create_string_buffer(16)
+    assert lib.snout_btle_format_line(rec.ctypes.data_as(C.c_void_p), 4e6, 0.0, 0, 0, buf, 16) == -1

@@ -90,3 +90,29 @@ def test_device_resident_input(rx, oracle):
     _same_packets(got, want)
     p = rx.profile()
     assert p.dominant_name == "btle_demod_corr" and p.ms_dominant > 0
+
+
+def test_cfg1_fixture_through_scan(tmp_path, oracle):
+    """cfg #1 plumbing: recorded ch37 file -> BtleScan -> btle_rx lines -> parser; 8/8 CRC0."""
+    import json
+    import os
+    from snout_amd.scan import BtleScan, FileSource
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    dump = tmp_path / "btle.b"
+    scan = BtleScan(channels=[37], source=FileSource(os.path.join(gold, "btle_ch37_4msps.cf32")),
+                    timeout=None, filename=str(dump), t0_epoch=1567108496.0)
+    seen = []
+    scan.events.on("btle.packet-received", lambda message: seen.append(message.sender))
+    msgs = scan.run()
+    truth = json.load(open(os.path.join(gold, "btle_ch37_truth.json")))
+    assert len(msgs) == 8 == len(seen)
+    for m, t in zip(msgs, truth):
+        pdu = bytes.fromhex(t["pdu"])
+        assert m.sender == pdu[2:8][::-1].hex() and m.payload_hex == pdu[8:].hex()
+        assert m.channel == "37"
+    cases = json.load(open(os.path.join(gold, "btle_lines.json")))
+    assert dump.read_bytes().decode() == "".join(c["line"] for c in cases[5:13])
+    # packet threshold stops the scan early, like check_stop (btle.py:111-122)
+    scan2 = BtleScan(channels=[37], source=FileSource(os.path.join(gold, "btle_ch37_4msps.cf32")),
+                     timeout=None, packet_threshold=3)
+    assert len(scan2.run()) == 3

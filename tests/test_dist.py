@@ -1,0 +1,76 @@
+"""Multi-GPU path on CPU: segment sharding, record dedup, and the record gather over a real
+world_size-2 gloo process group."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from snout_amd import dist as sdist
+from snout_amd._ffi import PKT_DTYPE
+
+
+def test_shard_segments_cover_everything_once():
+    n, seg, ov = 1000, 128, 40
+    for world in (1, 2, 3, 8):
+        segs = [sdist.shard_segments(n, seg, ov, r, world) for r in range(world)]
+        flat = sorted(s for rank in segs for s in rank)
+        assert [s[0] for s in flat] == list(range(0, n, seg))
+        assert all(b - a <= seg + ov and b <= n for a, b in flat)
+        assert all(flat[i][1] >= min(flat[i + 1][0] + ov, n) for i in range(len(flat) - 1))
+        counts = [len(r) for r in segs]
+        assert max(counts) - min(counts) <= 1
+
+
+def _recs(keys):
+    r = np.zeros(len(keys), dtype=PKT_DTYPE)
+    for i, (p, c, s) in enumerate(keys):
+        r[i]["proto"], r[i]["channel"], r[i]["sample_index"] = p, c, s
+        r[i]["bytes"][0] = i
+    return r
+
+
+def test_dedup_records():
+    r = _recs([(0, 37, 500), (0, 37, 100), (1, 11, 100), (0, 37, 500), (0, 38, 100), (0, 37, 100)])
+    d = sdist.dedup_records(r)
+    assert [(int(x["proto"]), int(x["channel"]), int(x["sample_index"])) for x in d] == \
+        [(0, 37, 100), (0, 37, 500), (0, 38, 100), (1, 11, 100)]
+    assert sdist.dedup_records(r[:0]).size == 0
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 3 if rank == 0 else 5
+        rec = _recs([(0, 37, 1000 * rank + i) for i in range(n)])
+        out = sdist.gather_records(rec)
+        empty = sdist.gather_records(rec[:0] if rank == 1 else rec[:1])
+        if rank == 0:
+            q.put((out["sample_index"].tolist(), empty["sample_index"].tolist()))
+        else:
+            assert out is None and empty is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_records_gloo_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, empty = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == [0, 1, 2, 1000, 1001, 1002, 1003, 1004]
+    assert empty == [0]
