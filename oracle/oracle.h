@@ -24,6 +24,19 @@ int      oracle_btle_segment(const float* iq, uint64_t n_samples, uint64_t first
                              snout_pkt* out, uint64_t cap, uint64_t* n_out,
                              uint64_t* hits_out, uint64_t hits_cap, uint64_t* n_hits_out);
 
+/* ---- Zigbee / IEEE 802.15.4 (oracle_zigbee.c) ---- */
+const uint32_t* oracle_zb_chip_map(void);
+const float*    oracle_zb_mmse_taps(void);
+float    oracle_fast_atan2f(float y, float x);
+void     oracle_zb_discrim(const float* iq, uint64_t n, float* d);
+uint16_t oracle_crc16_154(const uint8_t* d, int n);
+int      oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,
+                               uint32_t threshold, uint32_t core, uint32_t warmup,
+                               snout_pkt* out, uint64_t cap, uint64_t* n_out);
+int      oracle_zigbee_lane_soft(const float* iq, uint64_t n, uint32_t core, uint32_t warmup,
+                                 uint32_t lane, uint32_t threshold, float* z, float* chips,
+                                 uint64_t cap, uint64_t* n_chips);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,20 @@ def lib() -> C.CDLL:
                                              C.c_uint32, C.c_void_p, C.c_uint64, u64p,
                                              u64p, C.c_uint64, u64p]
         _lib.oracle_btle_segment.restype = C.c_int
+        _lib.oracle_zigbee_segment.argtypes = [f32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
+        _lib.oracle_zigbee_segment.restype = C.c_int
+        _lib.oracle_zigbee_lane_soft.argtypes = [f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, f32p, f32p, C.c_uint64, u64p]
+        _lib.oracle_zigbee_lane_soft.restype = C.c_int
+        _lib.oracle_zb_discrim.argtypes = [f32p, C.c_uint64, f32p]
+        _lib.oracle_zb_discrim.restype = None
+        _lib.oracle_fast_atan2f.argtypes = [C.c_float, C.c_float]
+        _lib.oracle_fast_atan2f.restype = C.c_float
+        _lib.oracle_zb_chip_map.restype = C.POINTER(C.c_uint32)
+        _lib.oracle_zb_mmse_taps.restype = C.POINTER(C.c_float)
+        _lib.oracle_crc16_154.argtypes = [u8p, C.c_int]
+        _lib.oracle_crc16_154.restype = C.c_uint16
     return _lib
 
 
@@ -129,3 +143,56 @@ def btle_segment(iq: np.ndarray, channel: int = 37, aa: int = 0x8E89BED6, crc_in
                                    _p(hits, C.c_uint64), hits.size, C.byref(n_hits))
     assert rc == 0, rc
     return out[:n_out.value], hits[:min(n_hits.value, hits.size)]
+
+
+# ---- Zigbee ------------------------------------------------------------------------------------
+def zb_chip_map() -> np.ndarray:
+    return np.array(lib().oracle_zb_chip_map()[:16], dtype=np.uint32)
+
+
+def zb_mmse_taps() -> np.ndarray:
+    return np.array(lib().oracle_zb_mmse_taps()[:129 * 8], dtype=np.float32).reshape(129, 8)
+
+
+def fast_atan2f(y: float, x: float) -> float:
+    return float(lib().oracle_fast_atan2f(y, x))
+
+
+def crc16_154(data: bytes) -> int:
+    a = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    return int(lib().oracle_crc16_154(_p(a, C.c_uint8), a.size))
+
+
+def zb_discrim(iq: np.ndarray) -> np.ndarray:
+    a = _f32(iq)
+    n = a.size // 2
+    d = np.zeros(max(n, 1), dtype=np.float32)
+    lib().oracle_zb_discrim(_p(a, C.c_float), n, _p(d, C.c_float))
+    return d[:n]
+
+
+def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 16384,
+                   warmup: int = 2048, first_sample_index: int = 0, cap: int = 0) -> np.ndarray:
+    a = _f32(iq)
+    n = a.size // 2
+    cap = cap or max(64, n // 512)
+    out = np.zeros(cap, dtype=PKT_DTYPE)
+    n_out = C.c_uint64(0)
+    rc = lib().oracle_zigbee_segment(_p(a, C.c_float), n, first_sample_index, channel, threshold,
+                                     core, warmup, out.ctypes.data_as(C.c_void_p), cap,
+                                     C.byref(n_out))
+    assert rc == 0, rc
+    return out[:n_out.value]
+
+
+def zigbee_lane_soft(iq: np.ndarray, lane: int = 0, core: int = 16384, warmup: int = 2048,
+                     threshold: int = 10, cap: int = 1 << 17):
+    a = _f32(iq)
+    n = a.size // 2
+    z = np.zeros(cap, dtype=np.float32)
+    chips = np.zeros(cap, dtype=np.float32)
+    nc = C.c_uint64(0)
+    rc = lib().oracle_zigbee_lane_soft(_p(a, C.c_float), n, core, warmup, lane, threshold,
+                                       _p(z, C.c_float), _p(chips, C.c_float), cap, C.byref(nc))
+    assert rc == 0
+    return z, chips[:min(nc.value, cap)]

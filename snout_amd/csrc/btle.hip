@@ -178,7 +178,6 @@ __global__ __launch_bounds__(256) void btle_corr_planes(
 // ---------------------------------------------------------------------------------------------
 // Block-level helpers (256 threads = 4 waves).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kScanItems;  // 1024
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, uint32_t lane)
 {
@@ -491,6 +490,14 @@ bool host_is_pinned(const void* p)
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return at.type == hipMemoryTypeHost;
+}
+
+void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fixed, uint32_t n_limit,
+                        uint32_t clamp, uint32_t* tile_sums, uint32_t* tile_over, uint32_t n_tiles,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(tile_reduce, dim3(n_tiles), dim3(256), 0, st, in, n_ptr, n_fixed, n_limit, clamp,
+                       tile_sums, tile_over);
 }
 
 int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_, uint32_t crc_init_,

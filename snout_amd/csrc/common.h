@@ -30,6 +30,8 @@ constexpr int kChunkIters = 64;     // iterations per chunk -> 16384 samples per
 constexpr int kChunkSamples = kIterSamples * kChunkIters;
 constexpr uint32_t kMaxTiles = 65536;                     // tile-sum table entries (1024 items each)
 constexpr size_t kTotalsBytes = (16 + 3 * kMaxTiles) * 4;
+constexpr uint32_t kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kScanItems;  // 1024
+constexpr int kSoftCap = 1 << 17;   // floats per soft-tap buffer (tests)
 constexpr int kBtleMaxSpan = 128 + 32 * (2 + 37 + 3);   // AA start -> end of CRC, samples
 
 // Candidate produced by the decode kernel, consumed by resolve/emit.
@@ -78,6 +80,34 @@ struct BtleCtx {
     int launch_corr_planes(uint64_t n, hipStream_t st);
     int finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt* out, uint64_t cap,
                uint64_t* n_out);
+};
+
+
+void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fixed, uint32_t n_limit,
+                        uint32_t clamp, uint32_t* tile_sums, uint32_t* tile_over, uint32_t n_tiles,
+                        hipStream_t st);
+
+// Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
+struct ZbCtx {
+    uint32_t n_slots = 0, threshold = 10, core = 16384, warmup = 2048;
+    uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
+    uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
+    uint64_t d_stride = 0;
+    bool overflow = false;
+    DevBuf d_atan, d_mmse, d_slot_channel, d_totals, d_d, d_stage, d_lane_cnt, d_out, d_soft;
+    uint32_t* h_totals = nullptr;
+    snout_pkt* h_out = nullptr;
+    uint64_t h_out_cap = 0;
+    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_t1 = nullptr;
+
+    int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
+             uint32_t warmup);
+    void destroy();
+    int reserve(uint64_t n_channel_samples);
+    int launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int soft_lane);
+    int run(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
+            snout_pkt* out, uint64_t cap, uint64_t* n_out);
+    int soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out);
 };
 
 }  // namespace snout

@@ -49,6 +49,7 @@ struct snout_rx {
     snout_rx_cfg cfg;
     int device = 0;
     BtleCtx btle;
+    ZbCtx zb;
     DevBuf d_iq;              // staging for snout_rx_process (host input)
     uint64_t last_n = 0;
     uint64_t last_pkts = 0;
@@ -116,6 +117,15 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         uint16_t ch = (uint16_t)c.channel;
         rc = h->btle.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
         if (rc) goto fail;
+    } else if (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 1) {
+        if (c.channel < 11 || c.channel > 26) { set_last_error("Zigbee channel %u", c.channel); goto fail; }
+        if (c.zb_core < 1024 || c.zb_core > (1u << 24) || c.zb_warmup > (1u << 20)) {
+            set_last_error("zb_core %u / zb_warmup %u out of range", c.zb_core, c.zb_warmup);
+            goto fail;
+        }
+        uint16_t ch = (uint16_t)c.channel;
+        rc = h->zb.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
+        if (rc) goto fail;
     } else {
         set_last_error("configuration proto=%u n_channels=%u not supported", c.proto, c.n_channels);
         goto fail;
@@ -124,6 +134,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     return SNOUT_OK;
 fail:
     h->btle.destroy();
+    h->zb.destroy();
     delete h;
     return rc;
 }
@@ -133,6 +144,7 @@ void snout_rx_destroy(snout_rx* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     h->btle.destroy();
+    h->zb.destroy();
     h->d_iq.release();
     delete h;
 }
@@ -160,6 +172,20 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
             // more hits than provisioned: grow and run the segment again (results never truncated)
             if (b.overflow_chunk) b.hit_cap = std::min<uint32_t>(b.hit_cap * 4u, kChunkSamples);
             if (b.overflow_cand) b.max_cand_grown = b.max_cand * 4u;
+        }
+        h->last_n = n_samples;
+        h->last_pkts = *n_out;
+        h->have_prof = true;
+        return rc;
+    }
+    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE && h->cfg.n_channels == 1) {
+        ZbCtx& z = h->zb;
+        int rc = 0;
+        for (int attempt = 0; attempt < 8; attempt++) {
+            if ((rc = z.reserve(n_samples))) return rc;
+            rc = z.run(iq_dev, n_samples, n_samples, first_sample_index, st, out, cap, n_out);
+            if (rc != SNOUT_EOVERFLOW || !z.overflow) break;
+            z.pkts_per_lane *= 4;       // a lane held more frames than provisioned: run again
         }
         h->last_n = n_samples;
         h->last_pkts = *n_out;
@@ -203,12 +229,21 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     if (!h || !out) return SNOUT_EINVAL;
     memset(out, 0, sizeof(*out));
     if (!h->have_prof) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
+    out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
+    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
+        ZbCtx& z = h->zb;
+        SNOUT_HIP(hipEventElapsedTime(&out->ms_total, z.ev_t0, z.ev_t1));
+        SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, z.ev_k0, z.ev_k1));
+        out->dominant_launches = 2;
+        out->n_hits = z.total_lanes;
+        snprintf(out->dominant_name, sizeof(out->dominant_name), "zb_discrim+zb_lanes");
+        return SNOUT_OK;
+    }
     BtleCtx& b = h->btle;
     SNOUT_HIP(hipEventElapsedTime(&out->ms_total, b.ev_t0, b.ev_t1));
     SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, b.ev_k0, b.ev_k1));
     out->dominant_launches = 1;
     out->n_hits = b.last_n_cand;
-    out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
     snprintf(out->dominant_name, sizeof(out->dominant_name), "btle_demod_corr");
     return SNOUT_OK;
 }
@@ -234,6 +269,11 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
             out[n] = (float)((pl[g * 4u + j] >> l) & 1ull);
         }
         return nb > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
+    }
+    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE && stage >= SNOUT_STAGE_ZB_DISCRIM &&
+        stage <= SNOUT_STAGE_ZB_CHIPS && h->cfg.n_channels == 1) {
+        if (h->last_n < 9) return SNOUT_EINVAL;
+        return h->zb.soft(stage, channel_slot, h->last_n, out, cap, n_out);
     }
     set_last_error("stage %u not available for this configuration", stage);
     return SNOUT_EINVAL;

@@ -1,0 +1,561 @@
+// zigbee.hip — IEEE 802.15.4 O-QPSK receive kernels for gfx950 (CDNA4, wave64).
+//
+// Replaces the GNU Radio receive flowgraph the reference spawns for `snout zigbee scan`
+// (snout/modulations/Zigbee/hackrf/Zigbee_rx/top_block.py:52-89):
+//   a4 quadrature_demod_cf(1)                       -> zb_discrim   (pointwise, HBM-bound)
+//   a5 x - single_pole_iir_filter_ff(0.00016)(x)    -> zb_lanes     (serial per lane, fp64 state)
+//   a6 clock_recovery_mm_ff(2, .000225, .5, .03, .0002)              (serial feedback loop)
+//   a7 ieee802_15_4.packet_sink(10)                                  (serial FSM)
+//
+// The feedback stages are inherently sequential, so parallelism comes from lanes: lane i owns the
+// core [i*core, (i+1)*core) of one channel, starts `warmup` samples early from the initial loop
+// state and runs past its core only to finish a frame whose preamble it found inside the core
+// (the same segmentation the oracle uses).  One wave = 64 lanes; a block is one wave.
+//
+// zb_lanes data flow per 64-sample tile:  HBM d[] --(64 coalesced 256-B row loads)--> LDS ring
+// (transposed, row stride 65 words: bank = (time + lane) mod 32, conflict-free) --> each lane runs
+// IIR, M&M and the sink over its own column.
+#include "common.h"
+
+namespace snout {
+
+// RX correlator words of gr-ieee802-15-4's packet_sink (FM-domain chip words, MSB = first chip).
+__constant__ uint32_t kChipMap[16] = {
+    1618456172u, 1309113062u, 1826650030u, 1724778362u, 778887287u, 2061946375u, 2007919840u,
+    125494990u,  529027475u,  838370585u,  320833617u,  422705285u, 1368596360u, 85537272u,
+    139563807u,  2021988657u};
+
+static const float kMmseTapsHost[129][8] = {
+#include "mmse_taps.inc"
+};
+
+// ---------------------------------------------------------------------------------------------
+// a4: d[t] = fast_atan2f(Im(x[t] conj x[t-1]), Re(...)),  x[-1] = 0.  GNU Radio's table-driven
+// fast_atan2f (257-entry atan table, linear interpolation, octant fix-up).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* __restrict__ tab)
+{
+    const float ya = fabsf(y), xa = fabsf(x);
+    if (!(ya > 0.0f || xa > 0.0f)) return 0.0f;
+    const float z = ya < xa ? ya / xa : xa / ya;
+    float base;
+    if (z < 0.003921569f) {
+        base = z;
+    } else {
+        float a = z * 255.0f;
+        const int k = ((int)a) & 0xff;
+        a -= (float)k;
+        const float t0 = tab[k];
+        base = t0 + (tab[k + 1] - t0) * a;
+    }
+    float ang;
+    if (xa > ya) {
+        if (x >= 0.0f) ang = y >= 0.0f ? base : -base;
+        else ang = y >= 0.0f ? 3.14159265358979323846f - base : base - 3.14159265358979323846f;
+    } else {
+        if (y >= 0.0f) ang = x >= 0.0f ? 1.57079632679489661923f - base : 1.57079632679489661923f + base;
+        else ang = x >= 0.0f ? -1.57079632679489661923f + base : -1.57079632679489661923f - base;
+    }
+    return ang;
+}
+
+__global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq, uint64_t n,
+                                                  uint64_t iq_stride, uint32_t n_slots,
+                                                  const float* __restrict__ atan_tab,
+                                                  float* __restrict__ d, uint64_t d_stride)
+{
+    __shared__ float tab[257];
+    for (uint32_t i = threadIdx.x; i < 257; i += 256) tab[i] = atan_tab[i];
+    __syncthreads();
+    const uint64_t total = n * n_slots;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * 256u) {
+        const uint64_t slot = g / n, t = g - slot * n;
+        const float2* x = iq + slot * iq_stride;
+        const float2 a = x[t];
+        const float2 p = t ? x[t - 1] : make_float2(0.0f, 0.0f);
+        const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
+        const float im = a.y * p.x - a.x * p.y;
+        d[slot * d_stride + t] = fast_atan2f_tab(im, re, tab);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5-a7: lanes.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingRows = 128;     // two 64-sample tiles
+constexpr int kRingStride = 65;
+
+struct SinkState {
+    int state;          // 0 search, 1 have_sync, 2 have_header
+    uint32_t shift;
+    int preamble_cnt, chip_cnt, packet_byte, byte_index, packetlen, packetlen_cnt, payload_cnt;
+    uint32_t lqi, lqi_cnt;
+    uint32_t trigger;   // lane-relative sample index of the first preamble match
+    uint32_t c0, c1, c2;   // running FCS: after all bytes, one byte ago, two bytes ago
+    uint32_t b_prev, b_last;   // the last two PSDU bytes
+};
+
+__device__ __forceinline__ void enter_search(SinkState& s)
+{
+    s.state = 0; s.shift = 0; s.preamble_cnt = 0; s.chip_cnt = 0; s.packet_byte = 0;
+}
+
+__device__ __forceinline__ uint32_t chip_dist(uint32_t shift, uint32_t word)
+{
+    return (uint32_t)__popc((shift & 0x7FFFFFFEu) ^ (word & 0x7FFFFFFEu));
+}
+
+__device__ __forceinline__ int decode_chips(SinkState& s, uint32_t th)
+{
+    int best = 0xFF;
+    uint32_t min_t = 33;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t t = chip_dist(s.shift, kChipMap[i]);
+        if (t < min_t) { best = i; min_t = t; }
+    }
+    if (min_t < th) {
+        if (s.lqi_cnt < 8) { s.lqi += 32 - min_t; s.lqi_cnt++; }
+        return best & 0xF;
+    }
+    return 0xFF;
+}
+
+__device__ __forceinline__ uint32_t crc16_step(uint32_t c, uint32_t byte)
+{
+    c ^= byte;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c = (c & 1u) ? ((c >> 1) ^ 0x8408u) : (c >> 1);
+    return c;
+}
+
+// Feed one chip.  Returns true when a frame completed (caller publishes, then enter_search).
+__device__ __forceinline__ bool sink_chip(SinkState& s, float chip, uint32_t at, uint32_t th,
+                                          uint8_t* __restrict__ pkt_bytes)
+{
+    s.shift = (s.shift << 1) | (chip > 0.0f ? 1u : 0u);
+    if (s.state == 0) {
+        if (s.preamble_cnt > 0) s.chip_cnt++;
+        if (s.preamble_cnt == 0) {
+            if (chip_dist(s.shift, kChipMap[0]) < th) {
+                s.preamble_cnt = 1;
+                s.trigger = at;
+            }
+        } else if (s.chip_cnt == 32) {
+            s.chip_cnt = 0;
+            if (s.packet_byte == 0) {
+                if (chip_dist(s.shift, kChipMap[0]) <= th) {
+                    s.preamble_cnt++;
+                } else if (chip_dist(s.shift, kChipMap[7]) <= th) {
+                    s.packet_byte = 7 << 4;
+                } else {
+                    enter_search(s);
+                }
+            } else {
+                if (chip_dist(s.shift, kChipMap[10]) <= th) {
+                    s.state = 1; s.packetlen_cnt = 0; s.packet_byte = 0; s.byte_index = 0;
+                    s.lqi = 0; s.lqi_cnt = 0;
+                } else {
+                    enter_search(s);
+                }
+            }
+        }
+        return false;
+    }
+    if (s.state == 1) {
+        s.chip_cnt++;
+        if (s.chip_cnt == 32) {
+            s.chip_cnt = 0;
+            const int c = decode_chips(s, th);
+            if (c == 0xFF) { enter_search(s); return false; }
+            if (s.byte_index == 0) s.packet_byte = c; else s.packet_byte |= c << 4;
+            s.byte_index++;
+            if ((s.byte_index & 1) == 0) {
+                const int len = s.packet_byte;
+                if (len <= 127) {
+                    s.state = 2; s.packetlen = len; s.payload_cnt = 0; s.packet_byte = 0;
+                    s.byte_index = 0; s.c0 = s.c1 = s.c2 = 0;
+                } else {
+                    enter_search(s);
+                }
+            }
+        }
+        return false;
+    }
+    s.chip_cnt = (s.chip_cnt + 1) & 31;
+    if (s.chip_cnt == 0) {
+        const int c = decode_chips(s, th);
+        if (c == 0xFF) { enter_search(s); return false; }
+        if (s.byte_index == 0) s.packet_byte = c; else s.packet_byte |= c << 4;
+        s.byte_index++;
+        if ((s.byte_index & 1) == 0) {
+            if (pkt_bytes) pkt_bytes[s.packetlen_cnt] = (uint8_t)s.packet_byte;
+            s.c2 = s.c1; s.c1 = s.c0; s.c0 = crc16_step(s.c0, (uint32_t)s.packet_byte);
+            s.b_prev = s.b_last; s.b_last = (uint32_t)s.packet_byte;
+            s.packetlen_cnt++;
+            s.payload_cnt++;
+            s.byte_index = 0;
+            if (s.payload_cnt >= s.packetlen) return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void zb_lanes(
+    const float* __restrict__ d, uint64_t n, uint64_t d_stride, uint32_t lanes_per_slot,
+    uint32_t total_lanes, uint32_t core, uint32_t warmup, uint32_t th,
+    const uint16_t* __restrict__ slot_channel, uint64_t first_index,
+    const float* __restrict__ mmse, snout_pkt* __restrict__ stage, uint32_t K,
+    uint32_t* __restrict__ lane_cnt, float* __restrict__ soft_z, float* __restrict__ soft_chips,
+    uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n)
+{
+    __shared__ float ring[kRingRows * kRingStride];
+    __shared__ float taps[129 * 8];
+    const uint32_t l = threadIdx.x;
+    for (uint32_t i = l; i < 129u * 8u; i += 64u) taps[i] = mmse[i];
+    const uint32_t g = blockIdx.x * 64u + l;
+    const bool active = g < total_lanes;
+    const uint32_t slot = active ? g / lanes_per_slot : 0u;
+    const uint32_t li = active ? g % lanes_per_slot : 0u;
+    const uint64_t core_start = (uint64_t)li * core;
+    const uint64_t s0 = core_start > warmup ? core_start - warmup : 0ull;
+    // lane-relative coordinates from here on (r = t - s0)
+    const uint32_t rel_core_start = (uint32_t)(core_start - s0);
+    const uint32_t rel_core_end = rel_core_start + core;
+    const uint64_t avail64 = active && n > s0 ? n - s0 : 0ull;
+    const uint32_t avail = avail64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)avail64;
+    const uint64_t base = (uint64_t)slot * d_stride + s0;     // offset of this lane's r = 0 in d
+    __syncthreads();
+
+    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+    const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
+    const float omega_lim = omega_mid * 0.0002f;
+    double lp = 0.0;
+    float mu = 0.5f, omega = 2.0f, last = 0.0f;
+    SinkState s;
+    enter_search(s);
+    s.byte_index = s.packetlen = s.packetlen_cnt = s.payload_cnt = 0;
+    s.lqi = s.lqi_cnt = 0; s.trigger = 0; s.c0 = s.c1 = s.c2 = 0; s.b_prev = s.b_last = 0;
+    uint32_t ii = 0;            // window start, lane-relative
+    uint32_t n_pk = 0, n_chips = 0;
+    bool done = !active || avail < 8u;
+    const bool tap = active && g == soft_lane && soft_chips != nullptr;
+
+    for (uint32_t tile = 0; ; tile++) {
+        if (__ballot(!done) == 0ull) break;
+        const uint32_t r0 = tile * 64u;
+        // ---- stage one 64-sample tile of every lane: row = lane whose samples are loaded
+        for (uint32_t row = 0; row < 64u; row++) {
+            const uint32_t b_lo = __shfl((uint32_t)base, (int)row);
+            const uint32_t b_hi = __shfl((uint32_t)(base >> 32), (int)row);
+            const uint32_t av = __shfl(done ? 0u : avail, (int)row);
+            const uint64_t rb = ((uint64_t)b_hi << 32) | b_lo;
+            const uint32_t r = r0 + l;
+            const float v = r < av ? d[rb + r] : 0.0f;
+            ring[((r & (kRingRows - 1)) * kRingStride) + row] = v;
+        }
+        __syncthreads();
+        if (!done) {
+            // ---- a5: DC removal, sequential over the new samples of this lane's column
+            const uint32_t hi = (r0 + 64u) < avail ? (r0 + 64u) : avail;
+            for (uint32_t r = r0; r < hi; r++) {
+                const uint32_t idx = (r & (kRingRows - 1)) * kRingStride + l;
+                const float x = ring[idx];
+                lp = alpha * (double)x + one_minus * lp;
+                const float z = x - (float)lp;
+                ring[idx] = z;
+                if (tap && soft_z && r < soft_cap) soft_z[r] = z;
+            }
+            // ---- a6 + a7 while the 8-tap window is filled
+            while (ii + 8u <= hi) {
+                const int imu = (int)rintf(mu * 128.0f);
+                const float* tp = &taps[imu * 8];
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
+                const float o = acc;
+                if (tap && n_chips < soft_cap) soft_chips[n_chips] = o;
+                n_chips++;
+                const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+                last = o;
+                omega = omega + gain_omega * mm;
+                {
+                    const float x = omega - omega_mid;
+                    const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+                    omega = omega_mid + c;
+                }
+                mu = mu + omega + gain_mu * mm;
+                const float fl = floorf(mu);
+                const uint32_t at = ii;
+                ii += (uint32_t)(int)fl;
+                mu = mu - fl;
+
+                const bool was_idle = (s.state == 0 && s.preamble_cnt == 0);
+                uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
+                const bool fin = sink_chip(s, o, at, th, pb);
+                if (was_idle && s.preamble_cnt == 1 && s.trigger >= rel_core_end) { done = true; break; }
+                if (fin) {
+                    if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
+                        if (n_pk < K) {
+                            snout_pkt* p = &stage[(size_t)g * K + n_pk];
+                            const uint32_t len = (uint32_t)s.packetlen_cnt;
+                            for (uint32_t b = len; b < 136u; b++) p->bytes[b] = 0;
+                            p->sample_index = first_index + s0 + s.trigger;
+                            p->proto = SNOUT_PROTO_ZIGBEE;
+                            p->channel = slot_channel[slot];
+                            p->len = (uint16_t)len;
+                            const uint32_t scaled = (s.lqi / 8u) << 3;
+                            p->lqi = (uint8_t)(scaled >= 256u ? 255u : scaled);
+                            p->pdu_type = 0;
+                            p->flags = 0;
+                            p->aux = li;
+                            // FCS: CRC-16 over all but the last two bytes == those two bytes (LE)
+                            const uint32_t rx = s.b_prev | (s.b_last << 8);
+                            p->crc_ok = (uint8_t)(len >= 3u && s.c2 == rx);
+                        }
+                        n_pk++;
+                    }
+                    enter_search(s);
+                }
+                if (s.state == 0 && s.preamble_cnt == 0 && ii >= rel_core_end) { done = true; break; }
+            }
+            if (hi >= avail && ii + 8u > avail) done = true;      // ran out of samples
+        }
+        __syncthreads();
+    }
+    if (active) lane_cnt[g] = n_pk;
+    if (tap && soft_n) *soft_n = n_chips;
+}
+
+// Ordered compaction of per-lane records: lane g holds min(lane_cnt[g], K) records.
+__global__ __launch_bounds__(256) void zb_emit(const snout_pkt* __restrict__ stage,
+                                               const uint32_t* __restrict__ lane_cnt, uint32_t K,
+                                               uint32_t total_lanes,
+                                               const uint32_t* __restrict__ tile_sums,
+                                               const uint32_t* __restrict__ tile_over,
+                                               uint32_t n_tiles, uint32_t* __restrict__ totals,
+                                               snout_pkt* __restrict__ out, uint32_t out_cap)
+{
+    __shared__ uint32_t lds[4];
+    auto block_sum = [&](const uint32_t* v, uint32_t cnt) -> uint32_t {
+        uint32_t x = 0;
+        for (uint32_t i = threadIdx.x; i < cnt; i += 256u) x += v[i];
+        // reduce across the block
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) x += __shfl_down(x, dlt);
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = x;
+        __syncthreads();
+        return lds[0] + lds[1] + lds[2] + lds[3];
+    };
+    const uint32_t tile = blockIdx.x;
+    if (tile == 0) {
+        const uint32_t all = block_sum(tile_sums, n_tiles);
+        const uint32_t over = block_sum(tile_over, n_tiles);
+        if (threadIdx.x == 0) { totals[1] = all; totals[2] = over; }
+    }
+    const uint32_t tile_base = block_sum(tile_sums, tile);
+    // 1024 lanes per tile, 4 per thread
+    const uint32_t g0 = tile * kScanTile + threadIdx.x * kScanItems;
+    uint32_t cnt[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t c = (g0 + k < total_lanes) ? lane_cnt[g0 + k] : 0u;
+        cnt[k] = c < K ? c : K;
+        s += cnt[k];
+    }
+    // exclusive scan of s over the block
+    uint32_t inc = s;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const uint32_t t = __shfl_up(inc, dlt);
+        if ((int)lane >= dlt) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wv] = inc;
+    __syncthreads();
+    uint32_t off = tile_base + inc - s;
+    for (uint32_t w = 0; w < wv; w++) off += lds[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        for (uint32_t i = 0; i < cnt[k]; i++) {
+            if (off < out_cap) {
+                const uint4* src = reinterpret_cast<const uint4*>(&stage[(size_t)(g0 + k) * K + i]);
+                uint4* dst = reinterpret_cast<uint4*>(&out[off]);
+#pragma unroll
+                for (int q = 0; q < 10; q++) dst[q] = src[q];
+            }
+            off++;
+        }
+    }
+}
+
+
+// =============================================================================================
+// Host side
+// =============================================================================================
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t threshold_, uint32_t core_,
+                uint32_t warmup_)
+{
+    n_slots = n_slots_;
+    threshold = threshold_;
+    core = core_;
+    warmup = warmup_;
+    std::vector<float> atan_tab(257);
+    for (int i = 0; i < 257; i++) atan_tab[i] = (float)atan((double)i / 255.0);
+    if (int rc = d_atan.ensure(257 * 4)) return rc;
+    if (int rc = d_mmse.ensure(129 * 8 * 4)) return rc;
+    if (int rc = d_slot_channel.ensure(n_slots * 2)) return rc;
+    if (int rc = d_totals.ensure(kTotalsBytes)) return rc;
+    SNOUT_HIP(hipMemcpy(d_atan.p, atan_tab.data(), 257 * 4, hipMemcpyHostToDevice));
+    SNOUT_HIP(hipMemcpy(d_mmse.p, kMmseTapsHost, 129 * 8 * 4, hipMemcpyHostToDevice));
+    SNOUT_HIP(hipMemcpy(d_slot_channel.p, slot_channel_, n_slots * 2, hipMemcpyHostToDevice));
+    SNOUT_HIP(hipHostMalloc((void**)&h_totals, 64, hipHostMallocDefault));
+    SNOUT_HIP(hipEventCreate(&ev_t0));
+    SNOUT_HIP(hipEventCreate(&ev_k0));
+    SNOUT_HIP(hipEventCreate(&ev_k1));
+    SNOUT_HIP(hipEventCreate(&ev_t1));
+    return 0;
+}
+
+void ZbCtx::destroy()
+{
+    d_atan.release(); d_mmse.release(); d_slot_channel.release(); d_totals.release();
+    d_d.release(); d_stage.release(); d_lane_cnt.release(); d_out.release(); d_soft.release();
+    if (h_totals) (void)hipHostFree(h_totals);
+    if (h_out) (void)hipHostFree(h_out);
+    h_totals = nullptr; h_out = nullptr; h_out_cap = 0;
+    if (ev_t0) { (void)hipEventDestroy(ev_t0); (void)hipEventDestroy(ev_k0);
+                 (void)hipEventDestroy(ev_k1); (void)hipEventDestroy(ev_t1); ev_t0 = nullptr; }
+}
+
+int ZbCtx::reserve(uint64_t n)
+{
+    lanes_per_slot = cdiv(n, core);
+    total_lanes = lanes_per_slot * n_slots;
+    d_stride = n + 64;
+    if (cdiv(total_lanes, 1024) > kMaxTiles) { set_last_error("too many lanes"); return SNOUT_ERANGE; }
+    if (int rc = d_d.ensure(d_stride * n_slots * 4u)) return rc;
+    if (int rc = d_stage.ensure((uint64_t)total_lanes * pkts_per_lane * sizeof(snout_pkt))) return rc;
+    if (int rc = d_lane_cnt.ensure(((uint64_t)total_lanes + 1024u) * 4u)) return rc;
+    max_out = total_lanes * pkts_per_lane;
+    if (int rc = d_out.ensure((uint64_t)max_out * sizeof(snout_pkt))) return rc;
+    if (int rc = d_soft.ensure(((uint64_t)kSoftCap * 2u + 16u) * 4u)) return rc;
+    return 0;
+}
+
+int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int soft_lane)
+{
+    float* sz = soft_lane >= 0 ? d_soft.as<float>() : nullptr;
+    float* sc = soft_lane >= 0 ? d_soft.as<float>() + kSoftCap : nullptr;
+    uint32_t* sn = soft_lane >= 0 ? (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap) : nullptr;
+    hipLaunchKernelGGL(zb_lanes, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
+                       d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
+                       d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
+                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), sz, sc,
+                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
+    SNOUT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Test tap: soft intermediates of one lane of the LAST processed segment (d is still resident).
+int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out)
+{
+    *n_out = 0;
+    if (stage_id == SNOUT_STAGE_ZB_DISCRIM) {
+        // `lane` selects the channel slot here
+        if (lane >= n_slots) return SNOUT_EINVAL;
+        const uint64_t m = n < cap ? n : cap;
+        SNOUT_HIP(hipMemcpy(out, d_d.as<float>() + (uint64_t)lane * d_stride, m * 4u, hipMemcpyDeviceToHost));
+        *n_out = n;
+        return n > cap ? SNOUT_EOVERFLOW : 0;
+    }
+    if (lane >= total_lanes) return SNOUT_EINVAL;
+    if (int rc = launch_lanes(n, 0, nullptr, (int)lane)) return rc;
+    SNOUT_HIP(hipDeviceSynchronize());
+    uint32_t nch = 0;
+    SNOUT_HIP(hipMemcpy(&nch, d_soft.as<float>() + 2 * kSoftCap, 4, hipMemcpyDeviceToHost));
+    if (stage_id == SNOUT_STAGE_ZB_CHIPS) {
+        const uint64_t have = nch < (uint32_t)kSoftCap ? nch : (uint32_t)kSoftCap;
+        const uint64_t m = have < cap ? have : cap;
+        SNOUT_HIP(hipMemcpy(out, d_soft.as<float>() + kSoftCap, m * 4u, hipMemcpyDeviceToHost));
+        *n_out = have;
+        return have > cap ? SNOUT_EOVERFLOW : 0;
+    }
+    if (stage_id == SNOUT_STAGE_ZB_DCREMOVED) {
+        // z is defined for every sample the lane filtered; report up to the tap capacity
+        const uint64_t li = lane % lanes_per_slot;
+        const uint64_t cs = li * (uint64_t)core, s0 = cs > warmup ? cs - warmup : 0;
+        uint64_t have = n > s0 ? n - s0 : 0;
+        have = std::min<uint64_t>(have, (uint64_t)warmup + core);     // always filtered that far
+        have = std::min<uint64_t>(have, kSoftCap);
+        const uint64_t m = have < cap ? have : cap;
+        SNOUT_HIP(hipMemcpy(out, d_soft.as<float>(), m * 4u, hipMemcpyDeviceToHost));
+        *n_out = have;
+        return have > cap ? SNOUT_EOVERFLOW : 0;
+    }
+    return SNOUT_EINVAL;
+}
+
+// iq: [n_slots][iq_stride] complex samples at 4 Msps per channel, device memory.
+int ZbCtx::run(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
+               snout_pkt* out, uint64_t cap, uint64_t* n_out)
+{
+    SNOUT_HIP(hipEventRecord(ev_t0, st));
+    uint32_t* tot = d_totals.as<uint32_t>();
+    uint32_t* sums = tot + 16;
+    uint32_t* over = tot + 16 + kMaxTiles;
+    SNOUT_HIP(hipEventRecord(ev_k0, st));
+    const uint32_t gd = std::min<uint32_t>(cdiv(n * n_slots, 256), 256u * 16u);
+    hipLaunchKernelGGL(zb_discrim, dim3(gd), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
+                       n_slots, d_atan.as<float>(), d_d.as<float>(), d_stride);
+    if (int rc = launch_lanes(n, first_index, st, -1)) return rc;
+    SNOUT_HIP(hipEventRecord(ev_k1, st));
+    const uint32_t n_tiles = cdiv(total_lanes, 1024);
+    launch_tile_reduce(d_lane_cnt.as<uint32_t>(), nullptr, total_lanes, total_lanes, pkts_per_lane,
+                       sums, over, n_tiles, st);
+    hipLaunchKernelGGL(zb_emit, dim3(n_tiles), dim3(256), 0, st, d_stage.as<snout_pkt>(),
+                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, total_lanes, sums, over, n_tiles, tot,
+                       d_out.as<snout_pkt>(), max_out);
+    SNOUT_HIP(hipGetLastError());
+    SNOUT_HIP(hipMemcpyAsync(h_totals, tot, 16, hipMemcpyDeviceToHost, st));
+    SNOUT_HIP(hipStreamSynchronize(st));
+    overflow = h_totals[2] != 0;
+    uint64_t np = h_totals[1];
+    *n_out = np;
+    if (overflow) {
+        set_last_error("more than %u frames in one lane", pkts_per_lane);
+        *n_out = 0;
+        SNOUT_HIP(hipEventRecord(ev_t1, st));
+        return SNOUT_EOVERFLOW;
+    }
+    int rc = 0;
+    if (np > cap) { np = cap; set_last_error("output capacity %llu < %u packets",
+                                             (unsigned long long)cap, h_totals[1]); rc = SNOUT_EOVERFLOW; }
+    if (np && host_is_pinned(out)) {
+        SNOUT_HIP(hipMemcpyAsync(out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
+        SNOUT_HIP(hipEventRecord(ev_t1, st));
+        SNOUT_HIP(hipStreamSynchronize(st));
+    } else if (np) {
+        if (h_out_cap < np) {
+            if (h_out) (void)hipHostFree(h_out);
+            h_out_cap = np + np / 2 + 1024;
+            SNOUT_HIP(hipHostMalloc((void**)&h_out, h_out_cap * sizeof(snout_pkt), hipHostMallocDefault));
+        }
+        SNOUT_HIP(hipMemcpyAsync(h_out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
+        SNOUT_HIP(hipEventRecord(ev_t1, st));
+        SNOUT_HIP(hipStreamSynchronize(st));
+        memcpy(out, h_out, np * sizeof(snout_pkt));
+    } else {
+        SNOUT_HIP(hipEventRecord(ev_t1, st));
+        SNOUT_HIP(hipStreamSynchronize(st));
+    }
+    return rc;
+}
+
+}  // namespace snout

@@ -168,3 +168,107 @@ def to_interleaved(x: np.ndarray) -> np.ndarray:
     """complex64[n] -> float32[2n] view (re, im interleaved), the on-disk/ABI layout."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     return x.view(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# IEEE 802.15.4 O-QPSK (2.4 GHz PHY)
+# ------------------------------------------------------------------------------------------------
+ZB_BASE_CHIPS = "11011001110000110101001000101110"   # symbol 0, c0..c31 (IEEE 802.15.4-2003 Table 24)
+
+
+def zb_chip_table() -> np.ndarray:
+    """16 x 32 chip values (0/1). Symbols 1..7 are symbol 0 cyclically shifted right by 4 chips
+    each; symbols 8..15 repeat 0..7 with the odd-indexed (Q) chips inverted."""
+    base = np.array([int(c) for c in ZB_BASE_CHIPS], dtype=np.uint8)
+    tab = np.zeros((16, 32), dtype=np.uint8)
+    for k in range(8):
+        tab[k] = np.roll(base, 4 * k)
+        tab[k + 8] = tab[k]
+        tab[k + 8][1::2] ^= 1
+    return tab
+
+
+def zb_chip_words() -> np.ndarray:
+    """FM-domain (MSK) chip words: d_k = c_{k-1} xor c_k xor (k & 1), first chip in the MSB.
+    Equal to gr-ieee802-15-4's CHIP_MAPPING under the mask 0x7FFFFFFE (c_{-1} taken as 0)."""
+    tab = zb_chip_table()
+    words = np.zeros(16, dtype=np.uint32)
+    for s in range(16):
+        prev = 0
+        w = 0
+        for k in range(32):
+            d = prev ^ int(tab[s][k]) ^ (k & 1)
+            w = (w << 1) | d
+            prev = int(tab[s][k])
+        words[s] = w
+    return words
+
+
+def crc16_154(data: bytes) -> int:
+    c = 0
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ 0x8408 if c & 1 else c >> 1
+    return c
+
+
+def zb_frame(psdu_wo_fcs: bytes) -> bytes:
+    """PSDU = payload + FCS (CRC-16 ITU-T, little-endian)."""
+    c = crc16_154(psdu_wo_fcs)
+    return bytes(psdu_wo_fcs) + bytes([c & 0xFF, c >> 8])
+
+
+def oqpsk_modulate(psdu: bytes, tail_symbols: int = 2) -> np.ndarray:
+    """SHR (4 x 0x00, SFD 0xA7) + PHR + PSDU -> complex64 at 4 samples per chip pair, following the
+    reference transmitter (Zigbee_tx/top_block.py:59-71): nibble (low first) -> 16 complex chips
+    -> repeat 4 -> x [0, sin(pi/4), 1, sin(3pi/4)] -> Q delayed by 2 samples."""
+    assert len(psdu) <= 127
+    ppdu = bytes([0, 0, 0, 0, 0xA7, len(psdu)]) + bytes(psdu)
+    tab = zb_chip_table()
+    chips = []
+    for b in ppdu:
+        chips.append(tab[b & 0xF])
+        chips.append(tab[b >> 4])
+    chips = np.concatenate(chips).astype(np.float64) * 2.0 - 1.0
+    i_ch = chips[0::2]
+    q_ch = chips[1::2]
+    shape = np.array([0.0, math.sin(math.pi / 4), 1.0, math.sin(3 * math.pi / 4)])
+    n = i_ch.size * 4 + 2 + 4 * 16 * tail_symbols
+    i_s = np.zeros(n)
+    q_s = np.zeros(n)
+    i_s[:i_ch.size * 4] = np.repeat(i_ch, 4) * np.tile(shape, i_ch.size)
+    q_s[2:2 + q_ch.size * 4] = np.repeat(q_ch, 4) * np.tile(shape, q_ch.size)
+    return (i_s + 1j * q_s).astype(np.complex64)
+
+
+def zigbee_capture(n_samples: int, channel: int = 11, seed: int = 4, mean_gap: float = 20000.0,
+                   sigma: float = 0.05, cfo_max_hz: float = 50e3, fs: float = 4e6,
+                   amplitude: float = 1.0, n_packets: Optional[int] = None, min_len: int = 5,
+                   max_len: int = 127, noise: bool = True, tail_guard: int = 4096
+                   ) -> Tuple[np.ndarray, List[TruthPacket]]:
+    """Single 802.15.4 channel at 4 Msps (2 samples/chip): AWGN + frames with valid FCS separated
+    by exponential gaps (SURVEY §8d cfg #4, per channel)."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros(n_samples, dtype=np.complex64)
+    truth: List[TruthPacket] = []
+    pos = int(rng.exponential(mean_gap)) + 512
+    while True:
+        if n_packets is not None and len(truth) >= n_packets:
+            break
+        ln = int(rng.integers(min_len, max_len + 1))
+        psdu = zb_frame(bytes(rng.integers(0, 256, ln - 2, dtype=np.uint8)))
+        wave = oqpsk_modulate(psdu)
+        if pos + wave.size + tail_guard > n_samples:
+            break
+        cfo = rng.uniform(-cfo_max_hz, cfo_max_hz)
+        ph0 = rng.uniform(0, 2 * math.pi)
+        nn = np.arange(wave.size)
+        rot = np.exp(1j * (2 * math.pi * cfo / fs * nn + ph0)).astype(np.complex64)
+        x[pos:pos + wave.size] += (amplitude * wave * rot).astype(np.complex64)
+        truth.append(TruthPacket(1, channel, pos, psdu, {"cfo": cfo}))
+        pos += wave.size + int(rng.exponential(mean_gap))
+    if noise and sigma > 0:
+        x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+              ).astype(np.complex64)
+    return x, truth
