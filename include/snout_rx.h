@@ -109,6 +109,10 @@ void snout_rx_destroy(snout_rx* h);
  * Packets are written in ascending (channel, sample_index) order. *n_out receives the number of
  * packets found (may exceed cap -> SNOUT_EOVERFLOW, first cap records valid).
  *
+ * Wideband handles (n_channels > 1): iq is the wideband capture; records carry the protocol
+ * channel of their bin and sample_index counts CHANNEL samples (4 Msps), first_sample_index is
+ * added as given (pass it in channel samples).
+ *
  * snout_rx_process      : iq in HOST memory; copied H->D (PCIe-inclusive path).
  * snout_rx_process_dev  : iq already resident in DEVICE memory (HBM); hip_stream is a hipStream_t
  *                         (NULL = the legacy default stream). out is HOST memory. */

@@ -37,6 +37,17 @@ int      oracle_zigbee_lane_soft(const float* iq, uint64_t n, uint32_t core, uin
                                  uint32_t lane, uint32_t threshold, float* z, float* chips,
                                  uint64_t cap, uint64_t* n_chips);
 
+/* ---- polyphase channelizer + wideband receivers (oracle_pfb.c) ---- */
+uint64_t oracle_pfb_nout(uint64_t n, uint32_t M);
+const float* oracle_pfb_proto(uint32_t M);
+int      oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride);
+uint32_t oracle_btle_bin_channel(uint32_t bin);
+uint32_t oracle_zigbee_bin_channel(uint32_t bin);
+int      oracle_wideband_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t proto,
+                                 uint32_t access_addr, uint32_t crc_init, uint32_t threshold,
+                                 uint32_t core, uint32_t warmup, snout_pkt* out, uint64_t cap,
+                                 uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

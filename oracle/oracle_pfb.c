@@ -1,0 +1,203 @@
+/*
+ * oracle_pfb.c — CPU statement of the polyphase FFT channelizer.  TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference has no channelizer: it observes one channel at a time and hops sequentially
+ * (snout/core/radio.py:415, snout/util/btle.py:62).  The channelizer is the north-star addition
+ * that lets one wideband capture feed every channel's demodulator at once (SURVEY §2.1, §8d
+ * cfg #3/#4), so there is no upstream arithmetic to follow; this file IS the specification, and
+ * the HIP kernel follows the same operation order so outputs are bit-identical f32.
+ *
+ * Definition (M channels, decimation D = M/2, P = 16 taps per branch, L = M P, prototype h):
+ *   u_m[r] = sum_{p=0}^{P-1} h[r + pM] x[mD + r + pM]         fmaf chain over ascending p
+ *   X_m[k] = sum_r u_m[r] e^{-2 pi i k r / M}                  two-factor FFT specified below
+ *   y_k[m] = (-1)^{k m} X_m[k]                                 (D = M/2 phase rotation)
+ * for m = 0 .. n_out-1, n_out = (n - L)/D + 1.  y_k is channel k (centre k fs/M) at 2 fs/M.
+ *
+ * FFT: n = M2 n1 + n2, k = k1 + M1 k2;  M = 40: M1 = 8, M2 = 5;  M = 16: M1 = M2 = 4.
+ *   A[n2][k1] = DFT_M1 over n1 (radix-2 DIT butterflies, exact +-1/+-i, sqrt(1/2) as one f32)
+ *   B[n2][k1] = A[n2][k1] W_M^{n2 k1}        re = fmaf(a,c,-(b d)), im = fmaf(a,d,b c)
+ *   X[k1 + M1 k2] = DFT_M2 over n2           M2 = 5: direct, fmaf chain; M2 = 4: butterflies
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+#include "pfb_tables.inc"
+
+typedef struct { float re, im; } cf;
+
+static inline cf cadd(cf a, cf b) { cf r = {a.re + b.re, a.im + b.im}; return r; }
+static inline cf csub(cf a, cf b) { cf r = {a.re - b.re, a.im - b.im}; return r; }
+static inline cf cmul_tw(cf a, float c, float d)
+{
+    cf r;
+    r.re = fmaf(a.re, c, -(a.im * d));
+    r.im = fmaf(a.re, d, a.im * c);
+    return r;
+}
+
+static void dft4(const cf b[4], cf X[4])
+{
+    const cf s0 = cadd(b[0], b[2]), s1 = csub(b[0], b[2]);
+    const cf s2 = cadd(b[1], b[3]), s3 = csub(b[1], b[3]);
+    X[0] = cadd(s0, s2);
+    X[2] = csub(s0, s2);
+    X[1].re = s1.re + s3.im; X[1].im = s1.im - s3.re;
+    X[3].re = s1.re - s3.im; X[3].im = s1.im + s3.re;
+}
+
+static void dft8(const cf a[8], cf X[8])
+{
+    const float c = 0.70710678118654752440f;
+    cf e[4] = {a[0], a[2], a[4], a[6]}, o[4] = {a[1], a[3], a[5], a[7]}, E[4], O[4], T[4];
+    dft4(e, E);
+    dft4(o, O);
+    T[0] = O[0];
+    T[1].re = (O[1].re + O[1].im) * c; T[1].im = (O[1].im - O[1].re) * c;
+    T[2].re = O[2].im;                 T[2].im = -O[2].re;
+    T[3].re = (O[3].im - O[3].re) * c; T[3].im = -((O[3].re + O[3].im) * c);
+    for (int k = 0; k < 4; k++) { X[k] = cadd(E[k], T[k]); X[k + 4] = csub(E[k], T[k]); }
+}
+
+static void dft5(const cf b[5], cf X[5])
+{
+    for (int k = 0; k < 5; k++) {
+        cf acc = b[0];
+        for (int n = 1; n < 5; n++) {
+            const int j = (n * k) % 5;
+            const float wr = kTw5[2 * j], wi = kTw5[2 * j + 1];
+            acc.re = fmaf(b[n].re, wr, acc.re);
+            acc.re = fmaf(-b[n].im, wi, acc.re);
+            acc.im = fmaf(b[n].re, wi, acc.im);
+            acc.im = fmaf(b[n].im, wr, acc.im);
+        }
+        X[k] = acc;
+    }
+}
+
+static void fft40(const cf* u, cf* X)
+{
+    cf B[5][8];
+    for (int n2 = 0; n2 < 5; n2++) {
+        cf a[8], A[8];
+        for (int n1 = 0; n1 < 8; n1++) a[n1] = u[5 * n1 + n2];
+        dft8(a, A);
+        for (int k1 = 0; k1 < 8; k1++) {
+            const int j = (n2 * k1) % 40;
+            B[n2][k1] = j ? cmul_tw(A[k1], kTw40[2 * j], kTw40[2 * j + 1]) : A[k1];
+        }
+    }
+    for (int k1 = 0; k1 < 8; k1++) {
+        cf b[5], Y[5];
+        for (int n2 = 0; n2 < 5; n2++) b[n2] = B[n2][k1];
+        dft5(b, Y);
+        for (int k2 = 0; k2 < 5; k2++) X[k1 + 8 * k2] = Y[k2];
+    }
+}
+
+static void fft16(const cf* u, cf* X)
+{
+    cf B[4][4];
+    for (int n2 = 0; n2 < 4; n2++) {
+        cf a[4], A[4];
+        for (int n1 = 0; n1 < 4; n1++) a[n1] = u[4 * n1 + n2];
+        dft4(a, A);
+        for (int k1 = 0; k1 < 4; k1++) {
+            const int j = (n2 * k1) % 16;
+            B[n2][k1] = j ? cmul_tw(A[k1], kTw16[2 * j], kTw16[2 * j + 1]) : A[k1];
+        }
+    }
+    for (int k1 = 0; k1 < 4; k1++) {
+        cf b[4], Y[4];
+        for (int n2 = 0; n2 < 4; n2++) b[n2] = B[n2][k1];
+        dft4(b, Y);
+        for (int k2 = 0; k2 < 4; k2++) X[k1 + 4 * k2] = Y[k2];
+    }
+}
+
+uint64_t oracle_pfb_nout(uint64_t n, uint32_t M)
+{
+    const uint64_t L = (uint64_t)M * 16u, D = M / 2u;
+    return n >= L ? (n - L) / D + 1u : 0u;
+}
+
+const float* oracle_pfb_proto(uint32_t M) { return M == 40 ? kPfbProto40 : (M == 16 ? kPfbProto16 : NULL); }
+
+/* y: [M][y_stride] interleaved complex floats (2 floats per sample) */
+int oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride)
+{
+    if (M != 40 && M != 16) return -1;
+    const float* h = oracle_pfb_proto(M);
+    const uint32_t D = M / 2, P = 16;
+    const uint64_t n_out = oracle_pfb_nout(n, M);
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < (int64_t)n_out; m++) {
+        cf u[40], X[40];
+        const float* x = iq + 2ull * (uint64_t)m * D;
+        for (uint32_t r = 0; r < M; r++) {
+            float ar = 0.0f, ai = 0.0f;
+            for (uint32_t p = 0; p < P; p++) {
+                const float c = h[r + p * M];
+                ar = fmaf(c, x[2 * (r + p * M)], ar);
+                ai = fmaf(c, x[2 * (r + p * M) + 1], ai);
+            }
+            u[r].re = ar; u[r].im = ai;
+        }
+        if (M == 40) fft40(u, X); else fft16(u, X);
+        for (uint32_t k = 0; k < M; k++) {
+            cf v = X[k];
+            if (k & (uint32_t)m & 1u) { v.re = -v.re; v.im = -v.im; }
+            y[2 * (k * y_stride + (uint64_t)m)] = v.re;
+            y[2 * (k * y_stride + (uint64_t)m) + 1] = v.im;
+        }
+    }
+    return 0;
+}
+
+/* ---- wideband receivers: channelize, then the per-channel oracle on every bin --------------- */
+static int32_t btle_rf_to_channel(uint32_t k)
+{
+    if (k == 0) return 37;
+    if (k == 12) return 38;
+    if (k == 39) return 39;
+    if (k >= 1 && k <= 11) return (int32_t)k - 1;
+    return (int32_t)k - 2;
+}
+
+/* bin b of the M = 40 channelizer (centre 2442 MHz) carries RF index (b + 20) mod 40 */
+uint32_t oracle_btle_bin_channel(uint32_t bin) { return (uint32_t)btle_rf_to_channel((bin + 20u) % 40u); }
+/* bin b of the M = 16 channelizer carries synthetic 802.15.4 channel 11 + (b + 8) mod 16 */
+uint32_t oracle_zigbee_bin_channel(uint32_t bin) { return 11u + (bin + 8u) % 16u; }
+
+int oracle_wideband_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t proto,
+                            uint32_t access_addr, uint32_t crc_init, uint32_t threshold,
+                            uint32_t core, uint32_t warmup, snout_pkt* out, uint64_t cap,
+                            uint64_t* n_out)
+{
+    *n_out = 0;
+    const uint32_t M = proto == 0 ? 40u : 16u;
+    const uint64_t nc = oracle_pfb_nout(n, M);
+    if (nc == 0) return 0;
+    float* y = (float*)malloc((size_t)M * nc * 2u * sizeof(float));
+    if (!y) return -3;
+    int rc = oracle_pfb(iq, n, M, y, nc);
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < M && rc == 0; b++) {
+        uint64_t got = 0;
+        const float* yc = y + 2ull * b * nc;
+        snout_pkt* dst = total < cap ? out + total : out;
+        const uint64_t room = total < cap ? cap - total : 0;
+        if (proto == 0)
+            rc = oracle_btle_segment(yc, nc, first_index, oracle_btle_bin_channel(b), access_addr,
+                                     crc_init, dst, room, &got, NULL, 0, NULL);
+        else
+            rc = oracle_zigbee_segment(yc, nc, first_index, oracle_zigbee_bin_channel(b), threshold,
+                                       core, warmup, dst, room, &got);
+        if (rc == -5) rc = 0;
+        total += got;
+    }
+    free(y);
+    *n_out = total;
+    return rc ? rc : (total > cap ? -5 : 0);
+}

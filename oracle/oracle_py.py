@@ -79,6 +79,20 @@ def lib() -> C.CDLL:
         _lib.oracle_zb_mmse_taps.restype = C.POINTER(C.c_float)
         _lib.oracle_crc16_154.argtypes = [u8p, C.c_int]
         _lib.oracle_crc16_154.restype = C.c_uint16
+        _lib.oracle_pfb_nout.argtypes = [C.c_uint64, C.c_uint32]
+        _lib.oracle_pfb_nout.restype = C.c_uint64
+        _lib.oracle_pfb_proto.argtypes = [C.c_uint32]
+        _lib.oracle_pfb_proto.restype = C.POINTER(C.c_float)
+        _lib.oracle_pfb.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint64]
+        _lib.oracle_pfb.restype = C.c_int
+        _lib.oracle_btle_bin_channel.argtypes = [C.c_uint32]
+        _lib.oracle_btle_bin_channel.restype = C.c_uint32
+        _lib.oracle_zigbee_bin_channel.argtypes = [C.c_uint32]
+        _lib.oracle_zigbee_bin_channel.restype = C.c_uint32
+        _lib.oracle_wideband_segment.argtypes = [f32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.c_uint64, u64p]
+        _lib.oracle_wideband_segment.restype = C.c_int
     return _lib
 
 
@@ -196,3 +210,46 @@ def zigbee_lane_soft(iq: np.ndarray, lane: int = 0, core: int = 16384, warmup: i
                                        _p(z, C.c_float), _p(chips, C.c_float), cap, C.byref(nc))
     assert rc == 0
     return z, chips[:min(nc.value, cap)]
+
+
+# ---- polyphase channelizer / wideband ------------------------------------------------------------
+def pfb_nout(n: int, M: int) -> int:
+    return int(lib().oracle_pfb_nout(n, M))
+
+
+def pfb_proto(M: int) -> np.ndarray:
+    return np.array(lib().oracle_pfb_proto(M)[:M * 16], dtype=np.float32)
+
+
+def pfb(iq: np.ndarray, M: int) -> np.ndarray:
+    """-> complex64 [M, n_out]"""
+    a = _f32(iq)
+    n = a.size // 2
+    no = pfb_nout(n, M)
+    y = np.zeros((M, max(no, 1) * 2), dtype=np.float32)
+    rc = lib().oracle_pfb(_p(a, C.c_float), n, M, _p(y, C.c_float), max(no, 1))
+    assert rc == 0
+    return y.view(np.complex64)[:, :no]
+
+
+def btle_bin_channel(b: int) -> int:
+    return int(lib().oracle_btle_bin_channel(b))
+
+
+def zigbee_bin_channel(b: int) -> int:
+    return int(lib().oracle_zigbee_bin_channel(b))
+
+
+def wideband_segment(iq: np.ndarray, proto: int, first_sample_index: int = 0, aa: int = 0x8E89BED6,
+                     crc_init: int = 0x555555, threshold: int = 10, core: int = 16384,
+                     warmup: int = 2048, cap: int = 0) -> np.ndarray:
+    a = _f32(iq)
+    n = a.size // 2
+    cap = cap or max(256, n // 128)
+    out = np.zeros(cap, dtype=PKT_DTYPE)
+    n_out = C.c_uint64(0)
+    rc = lib().oracle_wideband_segment(_p(a, C.c_float), n, first_sample_index, proto, aa, crc_init,
+                                       threshold, core, warmup, out.ctypes.data_as(C.c_void_p), cap,
+                                       C.byref(n_out))
+    assert rc == 0, rc
+    return out[:n_out.value]

@@ -85,7 +85,9 @@ void oracle_zb_discrim(const float* iq, uint64_t n, float* d)
         const float ar = iq[2 * t], ai = iq[2 * t + 1];
         const float re = ar * pr + ai * pi;
         const float im = ai * pr - ar * pi;
-        d[t] = oracle_fast_atan2f(im, re);
+        float a = oracle_fast_atan2f(im, re);
+        if (!(fabsf(a) <= 4.0f)) a = 0.0f;      /* non-finite input: defined as 0 (stated deviation) */
+        d[t] = a;
         pr = ar;
         pi = ai;
     }

@@ -73,13 +73,17 @@ __device__ __forceinline__ void append_hits(const bool hit[4], uint32_t lane, ui
 // a1: demodulate + correlate, single narrowband channel.  One wave per 16384-sample chunk.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void btle_demod_corr(
-    const float* __restrict__ iq, uint64_t n_samples, uint32_t aa, uint32_t n_chunks,
-    uint64_t* __restrict__ planes, uint32_t* __restrict__ chunk_cnt,
-    uint32_t* __restrict__ chunk_hits, uint32_t cap)
+    const float* __restrict__ iq_all, uint64_t n_samples, uint64_t iq_stride, uint32_t aa,
+    uint32_t n_chunks, uint64_t* __restrict__ planes_all, uint64_t plane_stride,
+    uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_hits, uint32_t cap)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t chunk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (chunk >= n_chunks) return;
+    const uint32_t slot = blockIdx.y;                       // channel slot (1 for narrowband input)
+    const float* iq = iq_all + 2ull * slot * iq_stride;
+    uint64_t* planes = planes_all + (size_t)slot * plane_stride;
+    const uint32_t list_id = slot * n_chunks + chunk;
     const uint64_t nb = n_samples - 4u;                       // bits exist for n in [0, nb)
     const uint32_t it0 = chunk * (uint32_t)kChunkIters;       // first iteration of this chunk
     const uint32_t itw = it0 - (chunk > 0 ? 1u : 0u);         // warm-up iteration (history only)
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
     uint64_t prev[4] = {0, 0, 0, 0};
     uint64_t keep[4] = {0, 0, 0, 0};
     uint32_t cnt = 0;
-    uint32_t* list = chunk_hits + (size_t)chunk * cap;
+    uint32_t* list = chunk_hits + (size_t)list_id * cap;
     const uint32_t n_it = (uint32_t)kChunkIters + (it0 - itw);
 
     for (uint32_t r = 0; r < n_it; r++) {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
     uint64_t* dst = planes + ((size_t)it0 + lane) * 4u;
     reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(keep[0], keep[1]);
     reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(keep[2], keep[3]);
-    if (lane == 0) chunk_cnt[chunk] = cnt;
+    if (lane == 0) chunk_cnt[list_id] = cnt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,12 +584,12 @@ int BtleCtx::begin(hipStream_t st)
 }
 
 // Narrowband front end: iq (device) -> planes + per-chunk hit lists.
-int BtleCtx::launch_demod_corr(const float* d_iq, uint64_t n, hipStream_t st)
+int BtleCtx::launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st)
 {
     SNOUT_HIP(hipEventRecord(ev_k0, st));
-    hipLaunchKernelGGL(btle_demod_corr, dim3(cdiv(n_chunks, 4)), dim3(256), 0, st, d_iq, n, aa,
-                       n_chunks, d_planes.as<uint64_t>(), d_chunk_cnt.as<uint32_t>(),
-                       d_chunk_hits.as<uint32_t>(), hit_cap);
+    hipLaunchKernelGGL(btle_demod_corr, dim3(cdiv(n_chunks, 4), n_slots), dim3(256), 0, st, d_iq, n,
+                       iq_stride, aa, n_chunks, d_planes.as<uint64_t>(), plane_stride,
+                       d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap);
     SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());
     return 0;

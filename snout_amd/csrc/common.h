@@ -76,7 +76,7 @@ struct BtleCtx {
     void destroy();
     int reserve(uint64_t n_channel_samples);
     int begin(hipStream_t st);
-    int launch_demod_corr(const float* d_iq, uint64_t n, hipStream_t st);
+    int launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st);
     int launch_corr_planes(uint64_t n, hipStream_t st);
     int finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt* out, uint64_t cap,
                uint64_t* n_out);
@@ -86,6 +86,18 @@ struct BtleCtx {
 void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fixed, uint32_t n_limit,
                         uint32_t clamp, uint32_t* tile_sums, uint32_t* tile_over, uint32_t n_tiles,
                         hipStream_t st);
+
+// Polyphase channelizer (pfb.hip): wideband cf32 -> [M][n_out] channel IQ at 2 fs/M.
+struct PfbCtx {
+    uint32_t M = 0;
+    uint64_t n_out = 0, y_stride = 0;
+    DevBuf d_proto, d_tw, d_tw5, d_y;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    int init(uint32_t M);
+    void destroy();
+    uint64_t n_out_for(uint64_t n) const;
+    int run(const float* d_iq, uint64_t n, hipStream_t st);
+};
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
 struct ZbCtx {

@@ -50,8 +50,11 @@ struct snout_rx {
     int device = 0;
     BtleCtx btle;
     ZbCtx zb;
+    PfbCtx pfb;
+    bool wide = false;
     DevBuf d_iq;              // staging for snout_rx_process (host input)
-    uint64_t last_n = 0;
+    uint64_t last_n = 0;      // input samples of the last segment
+    uint64_t last_nch = 0;    // channel samples per slot of the last segment
     uint64_t last_pkts = 0;
     bool have_prof = false;
 };
@@ -126,8 +129,24 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         uint16_t ch = (uint16_t)c.channel;
         rc = h->zb.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (rc) goto fail;
+    } else if ((c.proto == SNOUT_PROTO_BTLE && c.n_channels == 40) ||
+               (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 16)) {
+        // wideband: M-branch channelizer, every bin is a channel slot
+        h->wide = true;
+        const uint32_t M = c.n_channels;
+        uint16_t chs[40];
+        for (uint32_t b = 0; b < M; b++)
+            chs[b] = c.proto == SNOUT_PROTO_BTLE ? (uint16_t)snout_btle_rf_to_channel((b + 20u) % 40u)
+                                                 : (uint16_t)(11u + (b + 8u) % 16u);
+        if (c.taps_per_branch != 16) { set_last_error("taps_per_branch must be 16"); goto fail; }
+        rc = h->pfb.init(M);
+        if (rc) goto fail;
+        rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits)
+                                         : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
+        if (rc) goto fail;
     } else {
-        set_last_error("configuration proto=%u n_channels=%u not supported", c.proto, c.n_channels);
+        set_last_error("configuration proto=%u n_channels=%u not supported (BTLE: 1 or 40, "
+                       "Zigbee: 1 or 16)", c.proto, c.n_channels);
         goto fail;
     }
     *out = h;
@@ -135,6 +154,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
 fail:
     h->btle.destroy();
     h->zb.destroy();
+    h->pfb.destroy();
     delete h;
     return rc;
 }
@@ -145,6 +165,7 @@ void snout_rx_destroy(snout_rx* h)
     (void)hipSetDevice(h->device);
     h->btle.destroy();
     h->zb.destroy();
+    h->pfb.destroy();
     h->d_iq.release();
     delete h;
 }
@@ -160,34 +181,55 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
     if (n_samples < 5) return SNOUT_OK;
     SNOUT_HIP(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    if (h->cfg.proto == SNOUT_PROTO_BTLE && h->cfg.n_channels == 1) {
+    // wideband input: channelize into [M][n_ch] channel IQ, then run the per-channel path on it
+    const float* ch_iq = iq_dev;
+    uint64_t n_ch = n_samples, ch_stride = n_samples;
+    if (h->wide) {
+        n_ch = h->pfb.n_out_for(n_samples);
+        h->last_n = n_samples;
+        h->last_nch = n_ch;
+        if (n_ch < 5) { h->have_prof = false; return SNOUT_OK; }
+    }
+    if (h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = h->btle;
         int rc = 0;
         for (int attempt = 0; attempt < 12; attempt++) {
-            if ((rc = b.reserve(n_samples))) return rc;
+            if ((rc = b.reserve(n_ch))) return rc;
             if ((rc = b.begin(st))) return rc;
-            if ((rc = b.launch_demod_corr(iq_dev, n_samples, st))) return rc;
-            rc = b.finish(n_samples, first_sample_index, st, out, cap, n_out);
+            if (h->wide) {
+                if ((rc = h->pfb.run(iq_dev, n_samples, st))) return rc;
+                ch_iq = h->pfb.d_y.as<float>();
+                ch_stride = h->pfb.y_stride;
+            }
+            if ((rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st))) return rc;
+            rc = b.finish(n_ch, first_sample_index, st, out, cap, n_out);
             if (rc != SNOUT_EOVERFLOW || !(b.overflow_chunk || b.overflow_cand)) break;
             // more hits than provisioned: grow and run the segment again (results never truncated)
             if (b.overflow_chunk) b.hit_cap = std::min<uint32_t>(b.hit_cap * 4u, kChunkSamples);
             if (b.overflow_cand) b.max_cand_grown = b.max_cand * 4u;
         }
         h->last_n = n_samples;
+        h->last_nch = n_ch;
         h->last_pkts = *n_out;
         h->have_prof = true;
         return rc;
     }
-    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE && h->cfg.n_channels == 1) {
+    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
         ZbCtx& z = h->zb;
         int rc = 0;
         for (int attempt = 0; attempt < 8; attempt++) {
-            if ((rc = z.reserve(n_samples))) return rc;
-            rc = z.run(iq_dev, n_samples, n_samples, first_sample_index, st, out, cap, n_out);
+            if ((rc = z.reserve(n_ch))) return rc;
+            if (h->wide) {
+                if ((rc = h->pfb.run(iq_dev, n_samples, st))) return rc;
+                ch_iq = h->pfb.d_y.as<float>();
+                ch_stride = h->pfb.y_stride;
+            }
+            rc = z.run(ch_iq, n_ch, ch_stride, first_sample_index, st, out, cap, n_out);
             if (rc != SNOUT_EOVERFLOW || !z.overflow) break;
             z.pkts_per_lane *= 4;       // a lane held more frames than provisioned: run again
         }
         h->last_n = n_samples;
+        h->last_nch = n_ch;
         h->last_pkts = *n_out;
         h->have_prof = true;
         return rc;
@@ -230,6 +272,18 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     memset(out, 0, sizeof(*out));
     if (!h->have_prof) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
     out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
+    if (h->wide) {
+        // the channelizer is the dominant kernel of the wideband paths
+        BtleCtx& b = h->btle;
+        ZbCtx& z = h->zb;
+        const bool bt = h->cfg.proto == SNOUT_PROTO_BTLE;
+        SNOUT_HIP(hipEventElapsedTime(&out->ms_total, h->pfb.ev_k0, bt ? b.ev_t1 : z.ev_t1));
+        SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->pfb.ev_k0, h->pfb.ev_k1));
+        out->dominant_launches = 1;
+        out->n_hits = bt ? b.last_n_cand : z.total_lanes;
+        snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);
+        return SNOUT_OK;
+    }
     if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
         ZbCtx& z = h->zb;
         SNOUT_HIP(hipEventElapsedTime(&out->ms_total, z.ev_t0, z.ev_t1));
@@ -254,10 +308,19 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
     if (!h || !n_out) return SNOUT_EINVAL;
     *n_out = 0;
     SNOUT_HIP(hipSetDevice(h->device));
+    if (stage == SNOUT_STAGE_CHAN_IQ && h->wide) {
+        if (channel_slot >= h->pfb.M) return SNOUT_EINVAL;
+        const uint64_t nf = 2ull * h->pfb.n_out;
+        const uint64_t m = nf < cap ? nf : cap;
+        SNOUT_HIP(hipMemcpy(out, h->pfb.d_y.as<float>() + 2ull * channel_slot * h->pfb.y_stride, m * 4u,
+                            hipMemcpyDeviceToHost));
+        *n_out = nf;
+        return nf > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
+    }
     if (stage == SNOUT_STAGE_BTLE_BITS && h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = h->btle;
-        if (channel_slot >= b.n_slots || h->last_n < 5) return SNOUT_EINVAL;
-        const uint64_t nb = h->last_n - 4;
+        if (channel_slot >= b.n_slots || h->last_nch < 5) return SNOUT_EINVAL;
+        const uint64_t nb = h->last_nch - 4;
         const uint64_t words = (uint64_t)b.n_chunks * kChunkIters * 4u;
         std::vector<uint64_t> pl(words);
         SNOUT_HIP(hipMemcpy(pl.data(), b.d_planes.as<uint64_t>() + channel_slot * b.plane_stride,
@@ -271,9 +334,9 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
         return nb > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
     }
     if (h->cfg.proto == SNOUT_PROTO_ZIGBEE && stage >= SNOUT_STAGE_ZB_DISCRIM &&
-        stage <= SNOUT_STAGE_ZB_CHIPS && h->cfg.n_channels == 1) {
-        if (h->last_n < 9) return SNOUT_EINVAL;
-        return h->zb.soft(stage, channel_slot, h->last_n, out, cap, n_out);
+        stage <= SNOUT_STAGE_ZB_CHIPS) {
+        if (h->last_nch < 9) return SNOUT_EINVAL;
+        return h->zb.soft(stage, channel_slot, h->last_nch, out, cap, n_out);
     }
     set_last_error("stage %u not available for this configuration", stage);
     return SNOUT_EINVAL;

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
         const float2 p = t ? x[t - 1] : make_float2(0.0f, 0.0f);
         const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
         const float im = a.y * p.x - a.x * p.y;
-        d[slot * d_stride + t] = fast_atan2f_tab(im, re, tab);
+        float ang = fast_atan2f_tab(im, re, tab);
+        if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
+        d[slot * d_stride + t] = ang;
     }
 }
 
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
                 mu = mu + omega + gain_mu * mm;
                 const float fl = floorf(mu);
                 const uint32_t at = ii;
-                ii += (uint32_t)(int)fl;
+                ii += fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // fl is 1..3 for finite input
                 mu = mu - fl;
 
                 const bool was_idle = (s.state == 0 && s.preamble_cnt == 0);

@@ -272,3 +272,63 @@ def zigbee_capture(n_samples: int, channel: int = 11, seed: int = 4, mean_gap: f
         x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
               ).astype(np.complex64)
     return x, truth
+
+
+# ------------------------------------------------------------------------------------------------
+# Wideband compositor
+# ------------------------------------------------------------------------------------------------
+def _upsample_to_wideband(x: np.ndarray, up: int) -> np.ndarray:
+    """Integer-rate upsampling of a 4 Msps channel to the wideband rate (zero-stuff + windowed-sinc
+    low-pass, scipy.signal.resample_poly)."""
+    from scipy.signal import resample_poly
+    return resample_poly(x.astype(np.complex128), up, 1).astype(np.complex64)
+
+
+def btle_bin_channel(b: int) -> int:
+    """BLE channel index carried by bin b of the M = 40 channelizer centred at 2442 MHz."""
+    k = (b + 20) % 40
+    if k == 0:
+        return 37
+    if k == 12:
+        return 38
+    if k == 39:
+        return 39
+    return k - 1 if k <= 11 else k - 2
+
+
+def zigbee_bin_channel(b: int) -> int:
+    return 11 + (b + 8) % 16
+
+
+def wideband_capture(proto: int, n_samples: int, seed: int = 3, bins: Optional[Sequence[int]] = None,
+                     mean_gap: float = 20000.0, sigma: float = 0.05, cfo_max_hz: float = 50e3,
+                     max_len: int = 127) -> Tuple[np.ndarray, List[TruthPacket]]:
+    """Wideband synthetic capture (SURVEY §8d cfg #3 / #4): every listed channelizer bin carries an
+    independent narrowband 4 Msps traffic stream, upsampled by M/2... i.e. to fs = M * 2 MHz, shifted
+    to its bin centre (bin b -> b fs / M, wrapping) and summed; AWGN added at the wideband rate.
+    proto 0: BTLE, M = 40, fs = 80 Msps.  proto 1: 802.15.4, M = 16, fs = 32 Msps."""
+    M = 40 if proto == 0 else 16
+    up = M // 2
+    bins = list(range(M)) if bins is None else list(bins)
+    n_ch = n_samples // up
+    x = np.zeros(n_samples, dtype=np.complex64)
+    truth: List[TruthPacket] = []
+    t = np.arange(n_ch * up)
+    for b in bins:
+        if proto == 0:
+            ch = btle_bin_channel(b)
+            nb, tr = btle_capture(n_ch, channel=ch, seed=seed * 1000 + b, mean_gap=mean_gap,
+                                  noise=False, cfo_max_hz=cfo_max_hz)
+        else:
+            ch = zigbee_bin_channel(b)
+            nb, tr = zigbee_capture(n_ch, channel=ch, seed=seed * 1000 + b, mean_gap=mean_gap,
+                                    noise=False, cfo_max_hz=cfo_max_hz, max_len=max_len)
+        wb = _upsample_to_wideband(nb, up)
+        rot = np.exp(2j * np.pi * ((b * t) % M) / M).astype(np.complex64)
+        x[:wb.size] += wb * rot
+        truth.extend(tr)
+    if sigma > 0:
+        rng = np.random.default_rng(seed)
+        x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+              ).astype(np.complex64)
+    return x, truth
