@@ -178,9 +178,12 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
     *n_out = 0;
     h->have_prof = false;
     if (n_samples >= 0xFFFF0000ull) { set_last_error("segment of %llu samples", (unsigned long long)n_samples); return SNOUT_ERANGE; }
-    if (n_samples < 5) return SNOUT_OK;
     SNOUT_HIP(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)hip_stream;
+    if (n_samples < 5) {
+        if (h->wide) { h->pfb.n_out = 0; h->last_nch = 0; }
+        return SNOUT_OK;
+    }
     // wideband input: channelize into [M][n_ch] channel IQ, then run the per-channel path on it
     const float* ch_iq = iq_dev;
     uint64_t n_ch = n_samples, ch_stride = n_samples;
@@ -188,7 +191,12 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
         n_ch = h->pfb.n_out_for(n_samples);
         h->last_n = n_samples;
         h->last_nch = n_ch;
-        if (n_ch < 5) { h->have_prof = false; return SNOUT_OK; }
+        if (n_ch < 5) {     // too short for any demodulator; still channelize (soft tap)
+            h->have_prof = false;
+            if (int rc = h->pfb.run(iq_dev, n_samples, st)) return rc;
+            SNOUT_HIP(hipStreamSynchronize(st));
+            return SNOUT_OK;
+        }
     }
     if (h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = h->btle;
