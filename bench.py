@@ -151,6 +151,12 @@ def main():
         k_avg_ms = float(np.mean(k_ms))
         algo_bytes = 8.0 * n + 160.0 * len(local)
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath):       # PMC-derived HBM bytes per launch of the same workload
+            tj = json.load(open(tpath))
+            if tj.get("workload_samples") == n and tj.get("kernel") == prof.dominant_name:
+                traffic = tj["traffic_bytes_per_launch"]
         out = {
             "metric": "complex-IQ Msamples/s through BTLE demod+correlate+decode",
             "value": total_samples / dt / 1e6,
@@ -172,7 +178,9 @@ def main():
                        "sharding": "segments per rank, RCCL gather of 160-B records" if world > 1
                                    else "single segment"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
+                                           "gfx950-corrected)" if traffic else None,
                          "kernel": prof.dominant_name, "kernel_ms": k_avg_ms,
                          "algorithmic_bytes": algo_bytes},
         }
