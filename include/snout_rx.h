@@ -122,6 +122,16 @@ int  snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
                           uint64_t first_sample_index, void* hip_stream,
                           snout_pkt* out, uint64_t cap, uint64_t* n_out);
 
+/* Pipelined form: up to two segments may be in flight.  submit enqueues every kernel of a segment
+ * on hip_stream and returns without waiting; collect waits for the oldest submitted segment and
+ * hands out its records (collect_view: a pointer into the handle's pinned buffer, valid until two
+ * more submits).  The record D2H of segment i runs on an internal copy stream and overlaps the
+ * kernels of segment i+1.  iq_dev must stay valid and unchanged until its collect returns. */
+int  snout_rx_submit_dev  (snout_rx* h, const float* iq_dev, uint64_t n_samples,
+                           uint64_t first_sample_index, void* hip_stream);
+int  snout_rx_collect     (snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out);
+int  snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out);
+
 /* Page-locked host memory for `out`: records are then DMA'd straight into it (no staging copy).
  * Any other host pointer works too, through an internal pinned staging buffer. */
 void* snout_host_alloc(size_t bytes);
@@ -131,6 +141,9 @@ void  snout_host_free(void* p);
 int  snout_rx_soft   (snout_rx* h, uint32_t stage, uint32_t channel_slot,
                       float* out, uint64_t cap, uint64_t* n_out);
 int  snout_rx_profile(snout_rx* h, snout_rx_prof* out);
+/* Durations (ms, HIP events on the kernels' stream) of the dominant kernel of the last <= 64
+ * segments, oldest first.  Read after the fact so a pipelined run is not perturbed. */
+int  snout_rx_profile_history(snout_rx* h, float* ms, uint32_t cap, uint32_t* n_out);
 
 /* Host-side formatters for the two consumer contracts. */
 /* btle_rx stdout grammar (snout/core/message.py:214-215,226-236). Returns bytes written

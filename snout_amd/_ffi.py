@@ -20,7 +20,9 @@ STAGE_BTLE_BITS, STAGE_CHAN_IQ, STAGE_ZB_DISCRIM, STAGE_ZB_DCREMOVED, STAGE_ZB_C
 
 EXPORTS = [
     "snout_rx_create", "snout_rx_destroy", "snout_rx_process", "snout_rx_process_dev",
-    "snout_host_alloc", "snout_host_free", "snout_rx_soft", "snout_rx_profile", "snout_btle_format_line", "snout_rftap_encap",
+    "snout_rx_submit_dev", "snout_rx_collect", "snout_rx_collect_view",
+    "snout_host_alloc", "snout_host_free", "snout_rx_soft", "snout_rx_profile",
+    "snout_rx_profile_history", "snout_btle_format_line", "snout_rftap_encap",
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
     "snout_strerror", "snout_last_error", "snout_abi_version",
 ]
@@ -78,6 +80,12 @@ def load() -> C.CDLL:
     lib.snout_rx_process.restype = C.c_int
     lib.snout_rx_process_dev.argtypes = [vp, vp, u64, u64, vp, vp, u64, C.POINTER(u64)]
     lib.snout_rx_process_dev.restype = C.c_int
+    lib.snout_rx_submit_dev.argtypes = [vp, vp, u64, u64, vp]
+    lib.snout_rx_submit_dev.restype = C.c_int
+    lib.snout_rx_collect.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    lib.snout_rx_collect.restype = C.c_int
+    lib.snout_rx_collect_view.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.snout_rx_collect_view.restype = C.c_int
     lib.snout_host_alloc.argtypes = [C.c_size_t]
     lib.snout_host_alloc.restype = vp
     lib.snout_host_free.argtypes = [vp]
@@ -86,6 +94,8 @@ def load() -> C.CDLL:
     lib.snout_rx_soft.restype = C.c_int
     lib.snout_rx_profile.argtypes = [vp, C.POINTER(RxProf)]
     lib.snout_rx_profile.restype = C.c_int
+    lib.snout_rx_profile_history.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.snout_rx_profile_history.restype = C.c_int
     lib.snout_btle_format_line.argtypes = [vp, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
                                            C.c_char_p, C.c_size_t]
     lib.snout_btle_format_line.restype = C.c_int

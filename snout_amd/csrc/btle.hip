@@ -72,75 +72,99 @@ __device__ __forceinline__ void append_hits(const bool hit[4], uint32_t lane, ui
 // ---------------------------------------------------------------------------------------------
 // a1: demodulate + correlate, single narrowband channel.  One wave per 16384-sample chunk.
 // ---------------------------------------------------------------------------------------------
+// One wave processes one 16384-sample chunk.  DEPTH rows of 2 KiB are kept in flight per wave:
+// the loads of iteration r+DEPTH are issued before iteration r is processed.
+// (Measured and dropped, MI355X, 1e9 samples: non-temporal loads -40 % (they defeat the L1 reuse of
+//  the overlapping half of each lane's 64 B); taking the 4 following samples from the next lane by
+//  cross-lane shuffle instead of the overlapping load: +-0; a persistent grid pulling chunks from
+//  an atomic ticket: -5 %.  Software-pipelining the loads: +9 %.)
+template <int DEPTH>
 __global__ __launch_bounds__(256) void btle_demod_corr(
     const float* __restrict__ iq_all, uint64_t n_samples, uint64_t iq_stride, uint32_t aa,
-    uint32_t n_chunks, uint64_t* __restrict__ planes_all, uint64_t plane_stride,
+    uint32_t n_chunks, uint32_t n_slots, uint64_t* __restrict__ planes_all, uint64_t plane_stride,
     uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_hits, uint32_t cap)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t chunk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (chunk >= n_chunks) return;
-    const uint32_t slot = blockIdx.y;                       // channel slot (1 for narrowband input)
+    const uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (item >= n_chunks * n_slots) return;
+    const uint32_t slot = item / n_chunks, chunk = item - slot * n_chunks;
     const float* iq = iq_all + 2ull * slot * iq_stride;
     uint64_t* planes = planes_all + (size_t)slot * plane_stride;
-    const uint32_t list_id = slot * n_chunks + chunk;
+    uint32_t* list = chunk_hits + (size_t)item * cap;
+
     const uint64_t nb = n_samples - 4u;                       // bits exist for n in [0, nb)
     const uint32_t it0 = chunk * (uint32_t)kChunkIters;       // first iteration of this chunk
     const uint32_t itw = it0 - (chunk > 0 ? 1u : 0u);         // warm-up iteration (history only)
     const uint64_t base_sample = (uint64_t)itw * kIterSamples;
     const uint64_t rem = (n_samples - base_sample) * 8ull;
     const uint32_t recs = rem > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rem;
+    // wave-uniform descriptor; out-of-range reads return 0, so the tail needs no branches
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(iq + 2ull * base_sample), 0, (int)recs, 0x00020000);
 
     uint64_t prev[4] = {0, 0, 0, 0};
     uint64_t keep[4] = {0, 0, 0, 0};
     uint32_t cnt = 0;
-    uint32_t* list = chunk_hits + (size_t)list_id * cap;
     const uint32_t n_it = (uint32_t)kChunkIters + (it0 - itw);
 
-    for (uint32_t r = 0; r < n_it; r++) {
-        const uint32_t voff = r * 2048u + lane * 32u;
-        // samples 4l..4l+7 of this iteration: (I,Q) pairs, out-of-range reads return 0
-        const f32x4 v0 = buf_load16(rs, voff);
-        const f32x4 v1 = buf_load16(rs, voff + 16u);
-        const f32x4 v2 = buf_load16(rs, voff + 32u);
-        const f32x4 v3 = buf_load16(rs, voff + 48u);
-        // bit[n] = (I[n]*Q[n+4]) > (I[n+4]*Q[n]); two roundings, no contraction
-        bool b[4];
-        b[0] = (v0.x * v2.y) > (v2.x * v0.y);
-        b[1] = (v0.z * v2.w) > (v2.z * v0.w);
-        b[2] = (v1.x * v3.y) > (v3.x * v1.y);
-        b[3] = (v1.z * v3.w) > (v3.z * v1.w);
-        uint64_t cur[4];
+    auto ld = [&](uint32_t off) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    };
+    // samples 4l..4l+7 of a row: (I,Q) pairs; the upper half overlaps the next lane's lower half
+    f32x4 q[DEPTH][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) cur[j] = __ballot(b[j]);
+    for (int u = 0; u < DEPTH; u++) {
+        const uint32_t voff = (uint32_t)u * 2048u + lane * 32u;      // rows past n_it read as 0 or
+#pragma unroll                                                       // belong to the next chunk: unused
+        for (int k = 0; k < 4; k++) q[u][k] = ld(voff + 16u * k);
+    }
+    for (uint32_t r0 = 0; r0 < n_it; r0 += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; u++) {
+            const uint32_t r = r0 + (uint32_t)u;
+            if (r >= n_it) break;
+            const f32x4 v0 = q[u][0], v1 = q[u][1], v2 = q[u][2], v3 = q[u][3];
+            if (r + DEPTH < n_it) {
+                const uint32_t voff = (r + DEPTH) * 2048u + lane * 32u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[u][k] = ld(voff + 16u * k);
+            }
+            // bit[n] = (I[n]*Q[n+4]) > (I[n+4]*Q[n]); two roundings, no contraction
+            bool b[4];
+            b[0] = (v0.x * v2.y) > (v2.x * v0.y);
+            b[1] = (v0.z * v2.w) > (v2.z * v0.w);
+            b[2] = (v1.x * v3.y) > (v3.x * v1.y);
+            b[3] = (v1.z * v3.w) > (v3.z * v1.w);
+            uint64_t cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cur[j] = __ballot(b[j]);
 
-        const uint32_t it = itw + r;
-        if (it >= it0) {
-            const uint32_t n_base = it * (uint32_t)kIterSamples;
-            bool hit[4];
-            bool any = false;
+            const uint32_t it = itw + r;
+            if (it >= it0) {
+                const uint32_t n_base = it * (uint32_t)kIterSamples;
+                bool hit[4];
+                bool any = false;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t n = n_base + 4u * lane + (uint32_t)j;
-                hit[j] = (aa_window(prev[j], cur[j], lane) == aa) && n >= 124u && n < nb;
-                any |= hit[j];
-            }
-            if (__ballot(any) != 0ull) append_hits(hit, lane, n_base, list, cap, cnt);
-            if (lane == it - it0) {
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t n = n_base + 4u * lane + (uint32_t)j;
+                    hit[j] = (aa_window(prev[j], cur[j], lane) == aa) && n >= 124u && n < nb;
+                    any |= hit[j];
+                }
+                if (__ballot(any) != 0ull) append_hits(hit, lane, n_base, list, cap, cnt);
+                if (lane == it - it0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) keep[j] = cur[j];
+                    for (int j = 0; j < 4; j++) keep[j] = cur[j];
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) prev[j] = cur[j];
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) prev[j] = cur[j];
     }
     // one coalesced 2 KiB store of the chunk's bit planes: lane l holds iteration it0+l
     uint64_t* dst = planes + ((size_t)it0 + lane) * 4u;
     reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(keep[0], keep[1]);
     reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(keep[2], keep[3]);
-    if (lane == 0) chunk_cnt[list_id] = cnt;
+    if (lane == 0) chunk_cnt[item] = cnt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,13 +513,6 @@ namespace snout {
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-bool host_is_pinned(const void* p)
-{
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeHost;
-}
-
 void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fixed, uint32_t n_limit,
                         uint32_t clamp, uint32_t* tile_sums, uint32_t* tile_over, uint32_t n_tiles,
                         hipStream_t st)
@@ -511,6 +528,7 @@ int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_
     aa = aa_;
     crc_init = crc_init_;
     max_hits_cfg = max_hits_;
+    if (const char* e = getenv("SNOUT_K1_DEPTH")) variant = (uint32_t)atoi(e);
     // whitening sequences (LFSR x^7+x^4+1, position 0 = 1, positions 1..6 = channel MSB..LSB),
     // 48 bytes per slot packed LSB-first into six u64 words
     std::vector<uint64_t> wh(6u * n_slots, 0ull);
@@ -528,27 +546,16 @@ int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_
     }
     if (int rc = d_whiten.ensure(wh.size() * 8)) return rc;
     if (int rc = d_slot_channel.ensure(ch.size() * 2)) return rc;
-    if (int rc = d_totals.ensure(kTotalsBytes)) return rc;
     SNOUT_HIP(hipMemcpy(d_whiten.p, wh.data(), wh.size() * 8, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_slot_channel.p, ch.data(), ch.size() * 2, hipMemcpyHostToDevice));
-    SNOUT_HIP(hipHostMalloc((void**)&h_totals, 64, hipHostMallocDefault));
-    SNOUT_HIP(hipEventCreate(&ev_t0));
-    SNOUT_HIP(hipEventCreate(&ev_k0));
-    SNOUT_HIP(hipEventCreate(&ev_k1));
-    SNOUT_HIP(hipEventCreate(&ev_t1));
     return 0;
 }
 
 void BtleCtx::destroy()
 {
     d_planes.release(); d_chunk_cnt.release(); d_chunk_hits.release(); d_hit_n.release();
-    d_hit_slot.release(); d_cand.release(); d_stage.release(); d_accept.release(); d_out.release();
-    d_whiten.release(); d_slot_channel.release(); d_totals.release();
-    if (h_totals) (void)hipHostFree(h_totals);
-    if (h_out) (void)hipHostFree(h_out);
-    h_totals = nullptr; h_out = nullptr; h_out_cap = 0;
-    if (ev_t0) { (void)hipEventDestroy(ev_t0); (void)hipEventDestroy(ev_k0);
-                 (void)hipEventDestroy(ev_k1); (void)hipEventDestroy(ev_t1); ev_t0 = nullptr; }
+    d_hit_slot.release(); d_cand.release(); d_stage.release(); d_accept.release();
+    d_whiten.release(); d_slot_channel.release();
 }
 
 // Size every buffer for `n` channel-samples per slot.
@@ -571,26 +578,27 @@ int BtleCtx::reserve(uint64_t n)
     if (int rc = d_cand.ensure((uint64_t)max_cand * sizeof(BtleCand))) return rc;
     if (int rc = d_stage.ensure((uint64_t)max_cand * sizeof(snout_pkt))) return rc;
     if (int rc = d_accept.ensure(((uint64_t)max_cand + kScanTile) * 4u)) return rc;
-    if (int rc = d_out.ensure((uint64_t)max_cand * sizeof(snout_pkt))) return rc;
-    return 0;
-}
-
-// totals layout (u32): [0] n_cand  [1] n_out  [2] raw hit count  [16..16+kMaxTiles) list tile sums
-//                      [16+kMaxTiles ..) accept tile sums
-int BtleCtx::begin(hipStream_t st)
-{
-    SNOUT_HIP(hipEventRecord(ev_t0, st));
     return 0;
 }
 
 // Narrowband front end: iq (device) -> planes + per-chunk hit lists.
-int BtleCtx::launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st)
+int BtleCtx::launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
+                                ResultSlot* timing)
 {
-    SNOUT_HIP(hipEventRecord(ev_k0, st));
-    hipLaunchKernelGGL(btle_demod_corr, dim3(cdiv(n_chunks, 4), n_slots), dim3(256), 0, st, d_iq, n,
-                       iq_stride, aa, n_chunks, d_planes.as<uint64_t>(), plane_stride,
-                       d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap);
-    SNOUT_HIP(hipEventRecord(ev_k1, st));
+    const uint32_t total = n_chunks * n_slots;
+    if (timing) SNOUT_HIP(hipEventRecord(timing->ev_k0, st));
+#define SNOUT_K1(D)                                                                                  \
+    hipLaunchKernelGGL((btle_demod_corr<D>), dim3(cdiv(total, 4)), dim3(256), 0, st, d_iq, n, iq_stride, \
+                       aa, n_chunks, n_slots, d_planes.as<uint64_t>(), plane_stride,                  \
+                       d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap)
+    switch (variant) {          // prefetch depth; SNOUT_K1_DEPTH overrides for experiments
+        case 3: SNOUT_K1(3); break;
+        case 4: SNOUT_K1(4); break;
+        case 2: SNOUT_K1(2); break;
+        default: SNOUT_K1(1); break;
+    }
+#undef SNOUT_K1
+    if (timing) SNOUT_HIP(hipEventRecord(timing->ev_k1, st));
     SNOUT_HIP(hipGetLastError());
     return 0;
 }
@@ -605,12 +613,14 @@ int BtleCtx::launch_corr_planes(uint64_t n, hipStream_t st)
     return 0;
 }
 
-// Hit lists -> resolved, ordered packet records in host memory.
-int BtleCtx::finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt* out, uint64_t cap,
-                    uint64_t* n_out)
+// Hit lists -> resolved, ordered packet records in s.d_out; counts in s.d_totals.  No host sync.
+// totals (u32): [0] candidates  [1] packets  [2] chunks whose list overflowed
+//               [16 ..) list tile sums, [16+kMaxTiles ..) accept tile sums, [16+2 kMaxTiles ..) overflow
+int BtleCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s)
 {
+    if (int rc = s.d_out.ensure((uint64_t)max_cand * sizeof(snout_pkt))) return rc;
     const uint32_t lists = n_chunks * n_slots;
-    uint32_t* tot = d_totals.as<uint32_t>();
+    uint32_t* tot = s.d_totals.as<uint32_t>();
     uint32_t* list_tiles = tot + 16;
     uint32_t* acc_tiles = tot + 16 + kMaxTiles;
     uint32_t* over_tiles = tot + 16 + 2 * kMaxTiles;
@@ -632,48 +642,23 @@ int BtleCtx::finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt*
                        tot, 0u, max_cand, 1u, acc_tiles, (uint32_t*)nullptr);
     hipLaunchKernelGGL(btle_emit, dim3(n_cand_tiles), dim3(256), 0, st,
                        d_stage.as<snout_pkt>(), d_accept.as<uint32_t>(), acc_tiles, tot, max_cand,
-                       d_out.as<snout_pkt>(), max_cand);
+                       s.d_out.as<snout_pkt>(), max_cand);
     SNOUT_HIP(hipGetLastError());
-    SNOUT_HIP(hipMemcpyAsync(h_totals, tot, 16, hipMemcpyDeviceToHost, st));
-    SNOUT_HIP(hipStreamSynchronize(st));
-    last_n_cand = h_totals[0];
-    const uint32_t raw = h_totals[2];
-    uint64_t np = h_totals[1];
-    *n_out = np;
-    int rc = 0;
-    overflow_chunk = raw != 0;      // some chunk list was longer than hit_cap
-    overflow_cand = h_totals[0] > max_cand;
-    if (overflow_chunk || overflow_cand) {
-        // the caller (snout_rx_process_dev) grows the capacity and runs the segment again
-        set_last_error("BTLE hit capacity exceeded: %u candidates, per-chunk cap %u, max_cand %u",
-                       h_totals[0], hit_cap, max_cand);
-        *n_out = 0;
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        return SNOUT_EOVERFLOW;
-    }
-    if (np > cap) { np = cap; set_last_error("output capacity %llu < %u packets",
-                                             (unsigned long long)cap, h_totals[1]); rc = SNOUT_EOVERFLOW; }
-    if (np && host_is_pinned(out)) {
-        // caller's buffer is pinned (snout_host_alloc): DMA straight into it
-        SNOUT_HIP(hipMemcpyAsync(out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        SNOUT_HIP(hipStreamSynchronize(st));
-    } else if (np) {
-        // staged through pinned memory so the copy runs at full PCIe rate whatever `out` is
-        if (h_out_cap < np) {
-            if (h_out) (void)hipHostFree(h_out);
-            h_out_cap = np + np / 2 + 1024;
-            SNOUT_HIP(hipHostMalloc((void**)&h_out, h_out_cap * sizeof(snout_pkt), hipHostMallocDefault));
-        }
-        SNOUT_HIP(hipMemcpyAsync(h_out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        SNOUT_HIP(hipStreamSynchronize(st));
-        memcpy(out, h_out, np * sizeof(snout_pkt));
-    } else {
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        SNOUT_HIP(hipStreamSynchronize(st));
-    }
-    return rc;
+    return 0;
+}
+
+bool BtleCtx::check_overflow(const ResultSlot& s)
+{
+    last_n_cand = s.h_totals[0];
+    overflow_chunk = s.h_totals[2] != 0;      // some chunk list was longer than hit_cap
+    overflow_cand = s.h_totals[0] > max_cand;
+    if (!(overflow_chunk || overflow_cand)) return false;
+    // more hits than provisioned: grow; the caller runs the segment again (never truncated)
+    set_last_error("BTLE hit capacity exceeded: %u candidates, per-chunk cap %u, max_cand %u",
+                   s.h_totals[0], hit_cap, max_cand);
+    if (overflow_chunk) hit_cap = std::min<uint32_t>(hit_cap * 4u, kChunkSamples);
+    if (overflow_cand) max_cand_grown = max_cand * 4u;
+    return true;
 }
 
 }  // namespace snout

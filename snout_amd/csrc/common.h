@@ -57,29 +57,47 @@ struct DevBuf {
 
 
 
+// One in-flight result: device-side record buffer + totals, pinned host mirrors, events.
+// Two of them let the record D2H of segment i overlap the kernels of segment i+1.
+struct ResultSlot {
+    DevBuf d_out, d_totals;              // records; totals: [0] candidates/lanes [1] packets [2] overflow
+    uint32_t* h_totals = nullptr;        // pinned, 16 u32
+    snout_pkt* h_recs = nullptr;         // pinned staging for records
+    uint64_t h_cap = 0;
+    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_compute = nullptr, ev_copy = nullptr;
+    // bookkeeping of the submitted segment
+    const float* iq = nullptr;
+    uint64_t n_in = 0, first_index = 0, spec_copied = 0, n_pkts = 0;
+    hipStream_t stream = nullptr;
+    bool timed = false;
+    int hist_idx = 0;                    // event pair of the handle's pool that timed this segment
+    int init();
+    void destroy();
+    int ensure_host(uint64_t recs);
+};
+
 // BTLE pipeline state shared by the narrowband and the channelized front ends (btle.hip).
 struct BtleCtx {
     uint32_t n_slots = 0, aa = 0, crc_init = 0, max_hits_cfg = 0, max_cand_grown = 0;
     uint32_t n_chunks = 0, max_cand = 0, last_n_cand = 0;
     uint32_t hit_cap = 64;          // candidate hits one 16384-sample chunk can hold (grows on overflow)
     bool overflow_chunk = false, overflow_cand = false;
+    uint32_t variant = 1;           // btle_demod_corr prefetch depth (rows in flight per wave; 1 measured best)
     uint64_t plane_stride = 0;
     DevBuf d_planes, d_chunk_cnt, d_chunk_hits, d_hit_n, d_hit_slot, d_cand, d_stage, d_accept,
-        d_out, d_whiten, d_slot_channel, d_totals;
-    uint32_t* h_totals = nullptr;
-    snout_pkt* h_out = nullptr;
-    uint64_t h_out_cap = 0;
-    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_t1 = nullptr;
+        d_whiten, d_slot_channel;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t aa, uint32_t crc_init,
              uint32_t max_hits);
     void destroy();
     int reserve(uint64_t n_channel_samples);
-    int begin(hipStream_t st);
-    int launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st);
+    int launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
+                          ResultSlot* timing);
     int launch_corr_planes(uint64_t n, hipStream_t st);
-    int finish(uint64_t n, uint64_t first_index, hipStream_t st, snout_pkt* out, uint64_t cap,
-               uint64_t* n_out);
+    // hit lists -> ordered records in s.d_out, totals in s.d_totals (no host sync)
+    int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s);
+    // inspect the totals of a finished slot; true if capacity was exceeded (and grows it)
+    bool check_overflow(const ResultSlot& s);
 };
 
 
@@ -106,19 +124,17 @@ struct ZbCtx {
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
     uint64_t d_stride = 0;
     bool overflow = false;
-    DevBuf d_atan, d_mmse, d_slot_channel, d_totals, d_d, d_stage, d_lane_cnt, d_out, d_soft;
-    uint32_t* h_totals = nullptr;
-    snout_pkt* h_out = nullptr;
-    uint64_t h_out_cap = 0;
-    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_t1 = nullptr;
+    DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
              uint32_t warmup);
     void destroy();
     int reserve(uint64_t n_channel_samples);
     int launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int soft_lane);
-    int run(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
-            snout_pkt* out, uint64_t cap, uint64_t* n_out);
+    // discriminator + lanes + ordered compaction into s.d_out / s.d_totals (no host sync)
+    int enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
+                ResultSlot& s, bool time_front);
+    bool check_overflow(const ResultSlot& s);
     int soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out);
 };
 

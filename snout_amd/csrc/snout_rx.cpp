@@ -1,5 +1,6 @@
 // snout_rx.cpp — the C ABI of libsnout_rx.so (include/snout_rx.h): handle management, argument
-// checking, H->D staging for the host-pointer entry point, profiling read-back.
+// checking, the two-slot submit/collect pipeline (record D2H of segment i overlaps the kernels of
+// segment i+1 on a copy stream), H->D staging for the host-pointer entry point, profiling.
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
@@ -41,6 +42,50 @@ void DevBuf::release()
     cap = 0;
 }
 
+bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+int ResultSlot::init()
+{
+    if (int rc = d_totals.ensure(kTotalsBytes)) return rc;
+    SNOUT_HIP(hipHostMalloc((void**)&h_totals, 64, hipHostMallocDefault));
+    memset(h_totals, 0, 64);
+    SNOUT_HIP(hipEventCreate(&ev_t0));
+    SNOUT_HIP(hipEventCreate(&ev_k0));
+    SNOUT_HIP(hipEventCreate(&ev_k1));
+    SNOUT_HIP(hipEventCreate(&ev_compute));
+    SNOUT_HIP(hipEventCreate(&ev_copy));
+    return 0;
+}
+
+void ResultSlot::destroy()
+{
+    d_out.release();
+    d_totals.release();
+    if (h_totals) (void)hipHostFree(h_totals);
+    if (h_recs) (void)hipHostFree(h_recs);
+    h_totals = nullptr; h_recs = nullptr; h_cap = 0;
+    if (ev_t0) {
+        (void)hipEventDestroy(ev_t0); (void)hipEventDestroy(ev_k0); (void)hipEventDestroy(ev_k1);
+        (void)hipEventDestroy(ev_compute); (void)hipEventDestroy(ev_copy);
+        ev_t0 = nullptr;
+    }
+}
+
+int ResultSlot::ensure_host(uint64_t recs)
+{
+    if (recs <= h_cap) return 0;
+    if (h_recs) (void)hipHostFree(h_recs);
+    h_recs = nullptr;
+    h_cap = recs + recs / 4 + 1024;
+    SNOUT_HIP(hipHostMalloc((void**)&h_recs, h_cap * sizeof(snout_pkt), hipHostMallocDefault));
+    return 0;
+}
+
 }  // namespace snout
 
 using namespace snout;
@@ -48,16 +93,97 @@ using namespace snout;
 struct snout_rx {
     snout_rx_cfg cfg;
     int device = 0;
+    bool wide = false;
     BtleCtx btle;
     ZbCtx zb;
     PfbCtx pfb;
-    bool wide = false;
     DevBuf d_iq;              // staging for snout_rx_process (host input)
-    uint64_t last_n = 0;      // input samples of the last segment
-    uint64_t last_nch = 0;    // channel samples per slot of the last segment
-    uint64_t last_pkts = 0;
-    bool have_prof = false;
+    ResultSlot slots[2];
+    hipStream_t copy_stream = nullptr;
+    int head = 0, pending = 0;          // ring of submitted, not yet collected segments
+    uint64_t spec = 0;                  // records copied speculatively with the totals
+    // pool of event pairs around the dominant kernel: durations are read back after the fact
+    // (snout_rx_profile_history) so that timing does not perturb a pipelined run
+    static constexpr int kHist = 64;
+    hipEvent_t hist_k0[kHist] = {}, hist_k1[kHist] = {};
+    uint64_t hist_n = 0;                // segments submitted with timing
+    // last collected segment (profile / soft taps)
+    ResultSlot* last = nullptr;
+    uint64_t last_n = 0, last_nch = 0, last_pkts = 0;
 };
+
+// Enqueue every kernel of one segment on `st`, results into slot s.  No host synchronisation.
+static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
+{
+    const float* ch_iq = s.iq;
+    uint64_t n_ch = s.n_in, ch_stride = s.n_in;
+    SNOUT_HIP(hipEventRecord(s.ev_t0, st));
+    if (h->wide) {
+        n_ch = h->pfb.n_out_for(s.n_in);
+        SNOUT_HIP(hipEventRecord(s.ev_k0, st));
+        if (int rc = h->pfb.run(s.iq, s.n_in, st)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_k1, st));
+        ch_iq = h->pfb.d_y.as<float>();
+        ch_stride = h->pfb.y_stride;
+    }
+    if (h->cfg.proto == SNOUT_PROTO_BTLE) {
+        BtleCtx& b = h->btle;
+        if (int rc = b.reserve(n_ch)) return rc;
+        if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s)) return rc;
+        if (int rc = b.enqueue_tail(n_ch, s.first_index, st, s)) return rc;
+    } else {
+        ZbCtx& z = h->zb;
+        if (int rc = z.reserve(n_ch)) return rc;
+        if (int rc = z.enqueue(ch_iq, n_ch, ch_stride, s.first_index, st, s, !h->wide)) return rc;
+    }
+    SNOUT_HIP(hipEventRecord(s.ev_compute, st));
+    return 0;
+}
+
+// Totals (and `spec` records, speculatively) -> pinned host memory on the copy stream.
+static int enqueue_copy(snout_rx* h, ResultSlot& s, uint64_t spec)
+{
+    SNOUT_HIP(hipStreamWaitEvent(h->copy_stream, s.ev_compute, 0));
+    SNOUT_HIP(hipMemcpyAsync(s.h_totals, s.d_totals.p, 16, hipMemcpyDeviceToHost, h->copy_stream));
+    s.spec_copied = 0;
+    if (spec) {
+        const uint64_t room = s.d_out.cap / sizeof(snout_pkt);
+        spec = spec < room ? spec : room;
+        if (int rc = s.ensure_host(spec)) return rc;
+        SNOUT_HIP(hipMemcpyAsync(s.h_recs, s.d_out.p, spec * sizeof(snout_pkt), hipMemcpyDeviceToHost,
+                                 h->copy_stream));
+        s.spec_copied = spec;
+    }
+    SNOUT_HIP(hipEventRecord(s.ev_copy, h->copy_stream));
+    return 0;
+}
+
+// Wait for a slot; rerun with grown capacity on overflow.  On return the record count is known.
+static int finish_slot(snout_rx* h, ResultSlot& s)
+{
+    for (int attempt = 0; attempt < 12; attempt++) {
+        SNOUT_HIP(hipEventSynchronize(s.ev_copy));
+        const bool over = h->cfg.proto == SNOUT_PROTO_BTLE ? h->btle.check_overflow(s)
+                                                           : h->zb.check_overflow(s);
+        if (!over) { s.n_pkts = s.h_totals[1]; return SNOUT_OK; }
+        std::swap(s.ev_k0, h->hist_k0[s.hist_idx]);     // time the rerun with the same pool pair
+        std::swap(s.ev_k1, h->hist_k1[s.hist_idx]);
+        int rc = enqueue_segment(h, s, s.stream);
+        if (!rc) rc = enqueue_copy(h, s, 0);
+        std::swap(s.ev_k0, h->hist_k0[s.hist_idx]);
+        std::swap(s.ev_k1, h->hist_k1[s.hist_idx]);
+        if (rc) return rc;
+    }
+    return SNOUT_EOVERFLOW;
+}
+
+static void note_last(snout_rx* h, ResultSlot& s)
+{
+    h->last = &s;
+    h->last_n = s.n_in;
+    h->last_nch = h->wide ? h->pfb.n_out_for(s.n_in) : s.n_in;
+    h->last_pkts = s.n_pkts;
+}
 
 extern "C" {
 
@@ -115,6 +241,11 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     if (c.zb_warmup == 0) c.zb_warmup = 2048;
     if (c.n_channels == 0) c.n_channels = 1;
     int rc = SNOUT_EINVAL;
+    if (c.proto == SNOUT_PROTO_ZIGBEE &&
+        (c.zb_core < 1024 || c.zb_core > (1u << 24) || c.zb_warmup > (1u << 20))) {
+        set_last_error("zb_core %u / zb_warmup %u out of range", c.zb_core, c.zb_warmup);
+        goto fail;
+    }
     if (c.proto == SNOUT_PROTO_BTLE && c.n_channels == 1) {
         if (c.channel > 39) { set_last_error("BTLE channel %u", c.channel); goto fail; }
         uint16_t ch = (uint16_t)c.channel;
@@ -122,10 +253,6 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (rc) goto fail;
     } else if (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 1) {
         if (c.channel < 11 || c.channel > 26) { set_last_error("Zigbee channel %u", c.channel); goto fail; }
-        if (c.zb_core < 1024 || c.zb_core > (1u << 24) || c.zb_warmup > (1u << 20)) {
-            set_last_error("zb_core %u / zb_warmup %u out of range", c.zb_core, c.zb_warmup);
-            goto fail;
-        }
         uint16_t ch = (uint16_t)c.channel;
         rc = h->zb.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (rc) goto fail;
@@ -149,13 +276,26 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
                        "Zigbee: 1 or 16)", c.proto, c.n_channels);
         goto fail;
     }
+    for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
+    for (int i = 0; i < snout_rx::kHist; i++) {
+        if (hipEventCreate(&h->hist_k0[i]) != hipSuccess || hipEventCreate(&h->hist_k1[i]) != hipSuccess) {
+            rc = SNOUT_EHIP;
+            goto fail;
+        }
+    }
+    {   // highest priority: the short record copy must not queue behind the next segment's blocks
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+            set_last_error("hipStreamCreate failed");
+            rc = SNOUT_EHIP;
+            goto fail;
+        }
+    }
     *out = h;
     return SNOUT_OK;
 fail:
-    h->btle.destroy();
-    h->zb.destroy();
-    h->pfb.destroy();
-    delete h;
+    snout_rx_destroy(h);
     return rc;
 }
 
@@ -163,86 +303,154 @@ void snout_rx_destroy(snout_rx* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
     h->btle.destroy();
     h->zb.destroy();
     h->pfb.destroy();
     h->d_iq.release();
+    for (auto& s : h->slots) s.destroy();
+    for (int i = 0; i < snout_rx::kHist; i++) {
+        if (h->hist_k0[i]) (void)hipEventDestroy(h->hist_k0[i]);
+        if (h->hist_k1[i]) (void)hipEventDestroy(h->hist_k1[i]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
+}
+
+static int check_segment(snout_rx* h, const float* iq_dev, uint64_t n_samples)
+{
+    if (!h || (!iq_dev && n_samples)) return SNOUT_EINVAL;
+    if (n_samples >= 0xFFFF0000ull) {
+        set_last_error("segment of %llu samples", (unsigned long long)n_samples);
+        return SNOUT_ERANGE;
+    }
+    return SNOUT_OK;
+}
+
+// true if the segment is too short to hold anything (nothing enqueued)
+static bool too_short(snout_rx* h, uint64_t n_samples)
+{
+    const uint64_t n_ch = h->wide ? h->pfb.n_out_for(n_samples) : n_samples;
+    return n_ch < (h->cfg.proto == SNOUT_PROTO_BTLE ? 5u : 9u);
+}
+
+int snout_rx_submit_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
+                        uint64_t first_sample_index, void* hip_stream)
+{
+    if (int rc = check_segment(h, iq_dev, n_samples)) return rc;
+    if (h->pending >= 2) { set_last_error("two segments in flight: collect one first"); return SNOUT_EINVAL; }
+    SNOUT_HIP(hipSetDevice(h->device));
+    ResultSlot& s = h->slots[(h->head + h->pending) & 1];
+    s.iq = iq_dev;
+    s.n_in = n_samples;
+    s.first_index = first_sample_index;
+    s.stream = (hipStream_t)hip_stream;
+    s.n_pkts = 0;
+    s.timed = false;
+    if (too_short(h, n_samples)) {
+        // nothing to demodulate; still channelize so the soft tap of a wideband handle is defined
+        if (h->wide) {
+            h->pfb.n_out = 0;
+            if (n_samples) { if (int rc = h->pfb.run(iq_dev, n_samples, s.stream)) return rc; }
+        }
+        s.h_totals[0] = s.h_totals[1] = s.h_totals[2] = 0;
+        s.spec_copied = 0;
+        SNOUT_HIP(hipEventRecord(s.ev_copy, s.stream));
+    } else {
+        const int hi = (int)(h->hist_n % snout_rx::kHist);      // rotate the event pair of this slot
+        std::swap(s.ev_k0, h->hist_k0[hi]);
+        std::swap(s.ev_k1, h->hist_k1[hi]);
+        if (int rc = enqueue_segment(h, s, s.stream)) return rc;
+        if (int rc = enqueue_copy(h, s, h->spec)) return rc;
+        std::swap(s.ev_k0, h->hist_k0[hi]);                     // pool[hi] now holds this segment's pair
+        std::swap(s.ev_k1, h->hist_k1[hi]);
+        s.hist_idx = hi;
+        h->hist_n++;
+        s.timed = true;
+    }
+    h->pending++;
+    return SNOUT_OK;
+}
+
+int snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out)
+{
+    if (!h || !recs || !n_out) return SNOUT_EINVAL;
+    *recs = nullptr;
+    *n_out = 0;
+    if (h->pending == 0) { set_last_error("nothing submitted"); return SNOUT_EINVAL; }
+    SNOUT_HIP(hipSetDevice(h->device));
+    ResultSlot& s = h->slots[h->head];
+    h->head ^= 1;
+    h->pending--;
+    if (int rc = finish_slot(h, s)) return rc;
+    const uint64_t np = s.n_pkts;
+    if (np > s.spec_copied) {
+        // the speculative copy was short: fetch the rest (d_out of this slot is still intact)
+        std::vector<snout_pkt> keep;
+        if (s.spec_copied && np > s.h_cap) keep.assign(s.h_recs, s.h_recs + s.spec_copied);
+        if (int rc = s.ensure_host(np)) return rc;
+        if (!keep.empty()) memcpy(s.h_recs, keep.data(), keep.size() * sizeof(snout_pkt));
+        SNOUT_HIP(hipMemcpyAsync(s.h_recs + s.spec_copied, s.d_out.as<snout_pkt>() + s.spec_copied,
+                                 (np - s.spec_copied) * sizeof(snout_pkt), hipMemcpyDeviceToHost,
+                                 h->copy_stream));
+        SNOUT_HIP(hipEventRecord(s.ev_copy, h->copy_stream));
+        SNOUT_HIP(hipEventSynchronize(s.ev_copy));
+    }
+    h->spec = np + np / 8 + 64;        // next segment: copy this many with the totals
+    note_last(h, s);
+    *recs = s.h_recs;
+    *n_out = np;
+    return SNOUT_OK;
+}
+
+int snout_rx_collect(snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out)
+{
+    if (!out && cap) return SNOUT_EINVAL;
+    const snout_pkt* recs = nullptr;
+    uint64_t np = 0;
+    if (int rc = snout_rx_collect_view(h, &recs, &np)) return rc;
+    *n_out = np;
+    const uint64_t m = np < cap ? np : cap;
+    if (m) memcpy(out, recs, m * sizeof(snout_pkt));
+    if (np > cap) { set_last_error("output capacity %llu < %llu packets", (unsigned long long)cap,
+                                   (unsigned long long)np); return SNOUT_EOVERFLOW; }
+    return SNOUT_OK;
 }
 
 int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
                          uint64_t first_sample_index, void* hip_stream, snout_pkt* out, uint64_t cap,
                          uint64_t* n_out)
 {
-    if (!h || !n_out || (!out && cap) || (!iq_dev && n_samples)) return SNOUT_EINVAL;
+    if (!n_out || (!out && cap)) return SNOUT_EINVAL;
     *n_out = 0;
-    h->have_prof = false;
-    if (n_samples >= 0xFFFF0000ull) { set_last_error("segment of %llu samples", (unsigned long long)n_samples); return SNOUT_ERANGE; }
-    SNOUT_HIP(hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)hip_stream;
-    if (n_samples < 5) {
-        if (h->wide) { h->pfb.n_out = 0; h->last_nch = 0; }
-        return SNOUT_OK;
+    if (int rc = check_segment(h, iq_dev, n_samples)) return rc;
+    if (h->pending) { set_last_error("segments in flight: collect them first"); return SNOUT_EINVAL; }
+    // synchronous form: no speculation; records are DMA'd straight into `out` when it is pinned
+    const uint64_t spec_save = h->spec;
+    h->spec = 0;
+    int rc = snout_rx_submit_dev(h, iq_dev, n_samples, first_sample_index, hip_stream);
+    h->spec = spec_save;
+    if (rc) return rc;
+    ResultSlot& s = h->slots[h->head];
+    h->head ^= 1;
+    h->pending--;
+    if ((rc = finish_slot(h, s))) return rc;
+    uint64_t np = s.n_pkts;
+    *n_out = np;
+    note_last(h, s);
+    if (np > cap) { set_last_error("output capacity %llu < %llu packets", (unsigned long long)cap,
+                                   (unsigned long long)np); rc = SNOUT_EOVERFLOW; np = cap; }
+    if (np) {
+        snout_pkt* dst = out;
+        const bool direct = host_is_pinned(out);
+        if (!direct) { if (int r2 = s.ensure_host(np)) return r2; dst = s.h_recs; }
+        SNOUT_HIP(hipMemcpyAsync(dst, s.d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost,
+                                 h->copy_stream));
+        SNOUT_HIP(hipEventRecord(s.ev_copy, h->copy_stream));
+        SNOUT_HIP(hipEventSynchronize(s.ev_copy));
+        if (!direct) memcpy(out, s.h_recs, np * sizeof(snout_pkt));
     }
-    // wideband input: channelize into [M][n_ch] channel IQ, then run the per-channel path on it
-    const float* ch_iq = iq_dev;
-    uint64_t n_ch = n_samples, ch_stride = n_samples;
-    if (h->wide) {
-        n_ch = h->pfb.n_out_for(n_samples);
-        h->last_n = n_samples;
-        h->last_nch = n_ch;
-        if (n_ch < 5) {     // too short for any demodulator; still channelize (soft tap)
-            h->have_prof = false;
-            if (int rc = h->pfb.run(iq_dev, n_samples, st)) return rc;
-            SNOUT_HIP(hipStreamSynchronize(st));
-            return SNOUT_OK;
-        }
-    }
-    if (h->cfg.proto == SNOUT_PROTO_BTLE) {
-        BtleCtx& b = h->btle;
-        int rc = 0;
-        for (int attempt = 0; attempt < 12; attempt++) {
-            if ((rc = b.reserve(n_ch))) return rc;
-            if ((rc = b.begin(st))) return rc;
-            if (h->wide) {
-                if ((rc = h->pfb.run(iq_dev, n_samples, st))) return rc;
-                ch_iq = h->pfb.d_y.as<float>();
-                ch_stride = h->pfb.y_stride;
-            }
-            if ((rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st))) return rc;
-            rc = b.finish(n_ch, first_sample_index, st, out, cap, n_out);
-            if (rc != SNOUT_EOVERFLOW || !(b.overflow_chunk || b.overflow_cand)) break;
-            // more hits than provisioned: grow and run the segment again (results never truncated)
-            if (b.overflow_chunk) b.hit_cap = std::min<uint32_t>(b.hit_cap * 4u, kChunkSamples);
-            if (b.overflow_cand) b.max_cand_grown = b.max_cand * 4u;
-        }
-        h->last_n = n_samples;
-        h->last_nch = n_ch;
-        h->last_pkts = *n_out;
-        h->have_prof = true;
-        return rc;
-    }
-    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
-        ZbCtx& z = h->zb;
-        int rc = 0;
-        for (int attempt = 0; attempt < 8; attempt++) {
-            if ((rc = z.reserve(n_ch))) return rc;
-            if (h->wide) {
-                if ((rc = h->pfb.run(iq_dev, n_samples, st))) return rc;
-                ch_iq = h->pfb.d_y.as<float>();
-                ch_stride = h->pfb.y_stride;
-            }
-            rc = z.run(ch_iq, n_ch, ch_stride, first_sample_index, st, out, cap, n_out);
-            if (rc != SNOUT_EOVERFLOW || !z.overflow) break;
-            z.pkts_per_lane *= 4;       // a lane held more frames than provisioned: run again
-        }
-        h->last_n = n_samples;
-        h->last_nch = n_ch;
-        h->last_pkts = *n_out;
-        h->have_prof = true;
-        return rc;
-    }
-    return SNOUT_EINVAL;
+    return rc;
 }
 
 int snout_rx_process(snout_rx* h, const float* iq_host, uint64_t n_samples,
@@ -250,12 +458,13 @@ int snout_rx_process(snout_rx* h, const float* iq_host, uint64_t n_samples,
 {
     if (!h || !n_out || (!iq_host && n_samples)) return SNOUT_EINVAL;
     *n_out = 0;
-    if (n_samples < 5) return SNOUT_OK;
     SNOUT_HIP(hipSetDevice(h->device));
-    if (int rc = h->d_iq.ensure(n_samples * 8u)) return rc;
-    SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, n_samples * 8u, hipMemcpyHostToDevice));
-    return snout_rx_process_dev(h, h->d_iq.as<float>(), n_samples, first_sample_index, nullptr, out,
-                                cap, n_out);
+    if (n_samples) {
+        if (int rc = h->d_iq.ensure(n_samples * 8u)) return rc;
+        SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, n_samples * 8u, hipMemcpyHostToDevice));
+    }
+    return snout_rx_process_dev(h, n_samples ? h->d_iq.as<float>() : nullptr, n_samples,
+                                first_sample_index, nullptr, out, cap, n_out);
 }
 
 void* snout_host_alloc(size_t bytes)
@@ -278,35 +487,36 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
 {
     if (!h || !out) return SNOUT_EINVAL;
     memset(out, 0, sizeof(*out));
-    if (!h->have_prof) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
+    if (!h->last || !h->last->timed) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
+    ResultSlot& s = *h->last;
+    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, s.ev_t0, s.ev_copy));
+    SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->hist_k0[s.hist_idx], h->hist_k1[s.hist_idx]));
     out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
-    if (h->wide) {
-        // the channelizer is the dominant kernel of the wideband paths
-        BtleCtx& b = h->btle;
-        ZbCtx& z = h->zb;
-        const bool bt = h->cfg.proto == SNOUT_PROTO_BTLE;
-        SNOUT_HIP(hipEventElapsedTime(&out->ms_total, h->pfb.ev_k0, bt ? b.ev_t1 : z.ev_t1));
-        SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->pfb.ev_k0, h->pfb.ev_k1));
-        out->dominant_launches = 1;
-        out->n_hits = bt ? b.last_n_cand : z.total_lanes;
-        snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);
-        return SNOUT_OK;
-    }
-    if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
-        ZbCtx& z = h->zb;
-        SNOUT_HIP(hipEventElapsedTime(&out->ms_total, z.ev_t0, z.ev_t1));
-        SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, z.ev_k0, z.ev_k1));
-        out->dominant_launches = 2;
-        out->n_hits = z.total_lanes;
-        snprintf(out->dominant_name, sizeof(out->dominant_name), "zb_discrim+zb_lanes");
-        return SNOUT_OK;
-    }
-    BtleCtx& b = h->btle;
-    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, b.ev_t0, b.ev_t1));
-    SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, b.ev_k0, b.ev_k1));
+    out->n_hits = s.h_totals[0];
     out->dominant_launches = 1;
-    out->n_hits = b.last_n_cand;
-    snprintf(out->dominant_name, sizeof(out->dominant_name), "btle_demod_corr");
+    if (h->wide) {
+        snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);
+    } else if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
+        out->dominant_launches = 2;
+        snprintf(out->dominant_name, sizeof(out->dominant_name), "zb_discrim+zb_lanes");
+    } else {
+        snprintf(out->dominant_name, sizeof(out->dominant_name), "btle_demod_corr");
+    }
+    return SNOUT_OK;
+}
+
+int snout_rx_profile_history(snout_rx* h, float* ms, uint32_t cap, uint32_t* n_out)
+{
+    if (!h || !n_out || (!ms && cap)) return SNOUT_EINVAL;
+    *n_out = 0;
+    if (h->pending) { set_last_error("segments in flight"); return SNOUT_EINVAL; }
+    const uint64_t have = h->hist_n < (uint64_t)snout_rx::kHist ? h->hist_n : (uint64_t)snout_rx::kHist;
+    uint32_t k = 0;
+    for (uint64_t i = h->hist_n - have; i < h->hist_n && k < cap; i++, k++) {   // oldest first
+        const int hi = (int)(i % snout_rx::kHist);
+        SNOUT_HIP(hipEventElapsedTime(&ms[k], h->hist_k0[hi], h->hist_k1[hi]));
+    }
+    *n_out = k;
     return SNOUT_OK;
 }
 
@@ -315,13 +525,15 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
 {
     if (!h || !n_out) return SNOUT_EINVAL;
     *n_out = 0;
+    if (h->pending) { set_last_error("segments in flight"); return SNOUT_EINVAL; }
     SNOUT_HIP(hipSetDevice(h->device));
+    SNOUT_HIP(hipDeviceSynchronize());
     if (stage == SNOUT_STAGE_CHAN_IQ && h->wide) {
         if (channel_slot >= h->pfb.M) return SNOUT_EINVAL;
         const uint64_t nf = 2ull * h->pfb.n_out;
         const uint64_t m = nf < cap ? nf : cap;
-        SNOUT_HIP(hipMemcpy(out, h->pfb.d_y.as<float>() + 2ull * channel_slot * h->pfb.y_stride, m * 4u,
-                            hipMemcpyDeviceToHost));
+        if (m) SNOUT_HIP(hipMemcpy(out, h->pfb.d_y.as<float>() + 2ull * channel_slot * h->pfb.y_stride,
+                                   m * 4u, hipMemcpyDeviceToHost));
         *n_out = nf;
         return nf > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
     }

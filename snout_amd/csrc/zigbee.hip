@@ -244,20 +244,31 @@ __global__ __launch_bounds__(64) void zb_lanes(
     bool done = !active || avail < 8u;
     const bool tap = active && g == soft_lane && soft_chips != nullptr;
 
-    for (uint32_t tile = 0; ; tile++) {
-        if (__ballot(!done) == 0ull) break;
-        const uint32_t r0 = tile * 64u;
-        // ---- stage one 64-sample tile of every lane: row = lane whose samples are loaded
+    // Tile t+1 is fetched into registers (one value per row) while tile t is consumed from LDS.
+    float pre[64];
+    auto fetch_tile = [&](uint32_t r0) {
+#pragma unroll
         for (uint32_t row = 0; row < 64u; row++) {
             const uint32_t b_lo = __shfl((uint32_t)base, (int)row);
             const uint32_t b_hi = __shfl((uint32_t)(base >> 32), (int)row);
             const uint32_t av = __shfl(done ? 0u : avail, (int)row);
             const uint64_t rb = ((uint64_t)b_hi << 32) | b_lo;
             const uint32_t r = r0 + l;
-            const float v = r < av ? d[rb + r] : 0.0f;
-            ring[((r & (kRingRows - 1)) * kRingStride) + row] = v;
+            pre[row] = r < av ? d[rb + r] : 0.0f;
+        }
+    };
+    fetch_tile(0u);
+    for (uint32_t tile = 0; ; tile++) {
+        if (__ballot(!done) == 0ull) break;
+        const uint32_t r0 = tile * 64u;
+        // ---- stage the prefetched tile: thread l holds sample r0+l of every row (lane)
+        {
+            const uint32_t rr = ((r0 + l) & (kRingRows - 1)) * kRingStride;
+#pragma unroll
+            for (uint32_t row = 0; row < 64u; row++) ring[rr + row] = pre[row];
         }
         __syncthreads();
+        fetch_tile(r0 + 64u);       // in flight while this tile is processed
         if (!done) {
             // ---- a5: DC removal, sequential over the new samples of this lane's column
             const uint32_t hi = (r0 + 64u) < avail ? (r0 + 64u) : avail;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256) void zb_emit(const snout_pkt* __restrict__ sta
     if (tile == 0) {
         const uint32_t all = block_sum(tile_sums, n_tiles);
         const uint32_t over = block_sum(tile_over, n_tiles);
-        if (threadIdx.x == 0) { totals[1] = all; totals[2] = over; }
+        if (threadIdx.x == 0) { totals[0] = total_lanes; totals[1] = all; totals[2] = over; }
     }
     const uint32_t tile_base = block_sum(tile_sums, tile);
     // 1024 lanes per tile, 4 per thread
@@ -413,27 +424,16 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
     if (int rc = d_atan.ensure(257 * 4)) return rc;
     if (int rc = d_mmse.ensure(129 * 8 * 4)) return rc;
     if (int rc = d_slot_channel.ensure(n_slots * 2)) return rc;
-    if (int rc = d_totals.ensure(kTotalsBytes)) return rc;
     SNOUT_HIP(hipMemcpy(d_atan.p, atan_tab.data(), 257 * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_mmse.p, kMmseTapsHost, 129 * 8 * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_slot_channel.p, slot_channel_, n_slots * 2, hipMemcpyHostToDevice));
-    SNOUT_HIP(hipHostMalloc((void**)&h_totals, 64, hipHostMallocDefault));
-    SNOUT_HIP(hipEventCreate(&ev_t0));
-    SNOUT_HIP(hipEventCreate(&ev_k0));
-    SNOUT_HIP(hipEventCreate(&ev_k1));
-    SNOUT_HIP(hipEventCreate(&ev_t1));
     return 0;
 }
 
 void ZbCtx::destroy()
 {
-    d_atan.release(); d_mmse.release(); d_slot_channel.release(); d_totals.release();
-    d_d.release(); d_stage.release(); d_lane_cnt.release(); d_out.release(); d_soft.release();
-    if (h_totals) (void)hipHostFree(h_totals);
-    if (h_out) (void)hipHostFree(h_out);
-    h_totals = nullptr; h_out = nullptr; h_out_cap = 0;
-    if (ev_t0) { (void)hipEventDestroy(ev_t0); (void)hipEventDestroy(ev_k0);
-                 (void)hipEventDestroy(ev_k1); (void)hipEventDestroy(ev_t1); ev_t0 = nullptr; }
+    d_atan.release(); d_mmse.release(); d_slot_channel.release();
+    d_d.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
 }
 
 int ZbCtx::reserve(uint64_t n)
@@ -446,7 +446,6 @@ int ZbCtx::reserve(uint64_t n)
     if (int rc = d_stage.ensure((uint64_t)total_lanes * pkts_per_lane * sizeof(snout_pkt))) return rc;
     if (int rc = d_lane_cnt.ensure(((uint64_t)total_lanes + 1024u) * 4u)) return rc;
     max_out = total_lanes * pkts_per_lane;
-    if (int rc = d_out.ensure((uint64_t)max_out * sizeof(snout_pkt))) return rc;
     if (int rc = d_soft.ensure(((uint64_t)kSoftCap * 2u + 16u) * 4u)) return rc;
     return 0;
 }
@@ -504,60 +503,38 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     return SNOUT_EINVAL;
 }
 
-// iq: [n_slots][iq_stride] complex samples at 4 Msps per channel, device memory.
-int ZbCtx::run(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
-               snout_pkt* out, uint64_t cap, uint64_t* n_out)
+// iq: [n_slots][iq_stride] complex samples at 4 Msps per channel, device memory.  No host sync.
+// totals (u32): [0] lanes  [1] packets  [2] lanes that held more than pkts_per_lane frames
+int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
+                   ResultSlot& s, bool time_front)
 {
-    SNOUT_HIP(hipEventRecord(ev_t0, st));
-    uint32_t* tot = d_totals.as<uint32_t>();
+    if (int rc = s.d_out.ensure((uint64_t)max_out * sizeof(snout_pkt))) return rc;
+    uint32_t* tot = s.d_totals.as<uint32_t>();
     uint32_t* sums = tot + 16;
     uint32_t* over = tot + 16 + kMaxTiles;
-    SNOUT_HIP(hipEventRecord(ev_k0, st));
+    if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
     const uint32_t gd = std::min<uint32_t>(cdiv(n * n_slots, 256), 256u * 16u);
     hipLaunchKernelGGL(zb_discrim, dim3(gd), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
                        n_slots, d_atan.as<float>(), d_d.as<float>(), d_stride);
     if (int rc = launch_lanes(n, first_index, st, -1)) return rc;
-    SNOUT_HIP(hipEventRecord(ev_k1, st));
-    const uint32_t n_tiles = cdiv(total_lanes, 1024);
+    if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
+    const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
     launch_tile_reduce(d_lane_cnt.as<uint32_t>(), nullptr, total_lanes, total_lanes, pkts_per_lane,
                        sums, over, n_tiles, st);
     hipLaunchKernelGGL(zb_emit, dim3(n_tiles), dim3(256), 0, st, d_stage.as<snout_pkt>(),
                        d_lane_cnt.as<uint32_t>(), pkts_per_lane, total_lanes, sums, over, n_tiles, tot,
-                       d_out.as<snout_pkt>(), max_out);
+                       s.d_out.as<snout_pkt>(), max_out);
     SNOUT_HIP(hipGetLastError());
-    SNOUT_HIP(hipMemcpyAsync(h_totals, tot, 16, hipMemcpyDeviceToHost, st));
-    SNOUT_HIP(hipStreamSynchronize(st));
-    overflow = h_totals[2] != 0;
-    uint64_t np = h_totals[1];
-    *n_out = np;
-    if (overflow) {
-        set_last_error("more than %u frames in one lane", pkts_per_lane);
-        *n_out = 0;
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        return SNOUT_EOVERFLOW;
-    }
-    int rc = 0;
-    if (np > cap) { np = cap; set_last_error("output capacity %llu < %u packets",
-                                             (unsigned long long)cap, h_totals[1]); rc = SNOUT_EOVERFLOW; }
-    if (np && host_is_pinned(out)) {
-        SNOUT_HIP(hipMemcpyAsync(out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        SNOUT_HIP(hipStreamSynchronize(st));
-    } else if (np) {
-        if (h_out_cap < np) {
-            if (h_out) (void)hipHostFree(h_out);
-            h_out_cap = np + np / 2 + 1024;
-            SNOUT_HIP(hipHostMalloc((void**)&h_out, h_out_cap * sizeof(snout_pkt), hipHostMallocDefault));
-        }
-        SNOUT_HIP(hipMemcpyAsync(h_out, d_out.p, np * sizeof(snout_pkt), hipMemcpyDeviceToHost, st));
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        SNOUT_HIP(hipStreamSynchronize(st));
-        memcpy(out, h_out, np * sizeof(snout_pkt));
-    } else {
-        SNOUT_HIP(hipEventRecord(ev_t1, st));
-        SNOUT_HIP(hipStreamSynchronize(st));
-    }
-    return rc;
+    return 0;
+}
+
+bool ZbCtx::check_overflow(const ResultSlot& s)
+{
+    overflow = s.h_totals[2] != 0;
+    if (!overflow) return false;
+    set_last_error("more than %u frames in one lane", pkts_per_lane);
+    pkts_per_lane *= 4;       // a lane held more frames than provisioned: the caller runs it again
+    return true;
 }
 
 }  // namespace snout

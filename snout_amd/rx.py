@@ -114,6 +114,30 @@ class SnoutRx:
             self._h, C.c_void_p(iq.data_ptr()), n, first_sample_index, C.c_void_p(st), *r),
             cap=max(4096, n // 2048), copy=copy)
 
+    # ---- pipelined form: up to two segments in flight ---------------------------------------
+    def submit(self, iq, first_sample_index: int = 0, stream: Optional[int] = None) -> None:
+        """Enqueue one device-resident segment (torch CUDA tensor) without waiting. The tensor must
+        stay alive and unchanged until the matching :meth:`collect`."""
+        import torch
+        if not (isinstance(iq, torch.Tensor) and iq.is_cuda and iq.is_contiguous()):
+            raise TypeError("submit() needs a contiguous torch CUDA tensor")
+        n = iq.numel() if iq.dtype == torch.complex64 else iq.numel() // 2
+        st = stream if stream is not None else torch.cuda.current_stream(iq.device).cuda_stream
+        _ffi.check(self._lib.snout_rx_submit_dev(self._h, C.c_void_p(iq.data_ptr()), n,
+                                                 first_sample_index, C.c_void_p(st)))
+
+    def collect(self, copy: bool = True) -> np.ndarray:
+        """Records of the oldest submitted segment. ``copy=False``: a view of the handle's pinned
+        buffer, valid until two more submits."""
+        ptr = C.c_void_p()
+        n = C.c_uint64(0)
+        _ffi.check(self._lib.snout_rx_collect_view(self._h, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=PKT_DTYPE)
+        buf = (C.c_uint8 * (n.value * PKT_DTYPE.itemsize)).from_address(ptr.value)
+        view = np.frombuffer(buf, dtype=PKT_DTYPE)
+        return view.copy() if copy else view
+
     def soft(self, stage: int, channel_slot: int = 0, cap: int = 0) -> np.ndarray:
         cap = cap or (1 << 24)
         out = np.zeros(cap, dtype=np.float32)
@@ -128,6 +152,14 @@ class SnoutRx:
         _ffi.check(self._lib.snout_rx_profile(self._h, C.byref(p)))
         return Profile(p.ms_total, p.ms_dominant, p.dominant_launches, p.n_hits,
                        p.bytes_algorithmic, p.dominant_name.decode())
+
+
+    def profile_history(self) -> np.ndarray:
+        """Dominant-kernel durations (ms) of the last <= 64 segments, oldest first."""
+        ms = (C.c_float * 64)()
+        n = C.c_uint32(0)
+        _ffi.check(self._lib.snout_rx_profile_history(self._h, ms, 64, C.byref(n)))
+        return np.array(ms[:n.value], dtype=np.float64)
 
 
 def btle_format_line(pkt: np.void, fs_hz: float = 4e6, t0_epoch: float = 0.0, number: int = 0,

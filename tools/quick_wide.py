@@ -24,9 +24,11 @@ if "zb1" in which:
     t = torch.from_numpy(tile.view(np.float32)).cuda()
     rep = 24
     x = t.repeat(rep); x += 0.05 * torch.randn_like(x)
-    rx = SnoutRx(proto=1, channel=11)
-    run(f"zigbee 1ch (expect {rep*len(truth)})", rx, x, rep * tile.size)
-    del x, rx
+    for core in (16384, 4096):
+        rx = SnoutRx(proto=1, channel=11, zb_core=core)
+        run(f"zigbee 1ch core={core} (expect {rep*len(truth)})", rx, x, rep * tile.size)
+        del rx
+    del x
 if "btle40" in which:
     tile, truth = synth.wideband_capture(0, 40 * (1 << 16), seed=3, sigma=0.0)
     t = torch.from_numpy(tile.view(np.float32)).cuda()
