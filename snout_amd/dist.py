@@ -77,3 +77,110 @@ def gather_records(rec: np.ndarray, device=None, group=None) -> Optional[np.ndar
     host = allb.cpu().numpy().reshape(world, mx * REC)
     parts = [host[r, :int(counts_h[r]) * REC].view(PKT_DTYPE) for r in range(world)]
     return np.concatenate(parts)
+
+
+class AsyncRecordGather:
+    """Pipelined gather of packet records to rank 0.
+
+    ``start(rec)`` enqueues, on a side stream, the upload of this rank's records, ONE fixed-size
+    ``all_gather`` (RCCL over xGMI with the nccl backend) and, on rank 0, the download of the
+    gathered block into pinned host memory; ``finish()`` waits for the oldest started gather and
+    returns the records (rank 0) or None.  Two gathers may be in flight, so the exchange of step i
+    overlaps the kernels of step i+1.  Every rank sends ``cap`` record slots preceded by a header
+    slot holding its count; ``cap`` is agreed once (max over ranks + 25 %) and re-agreed only if a
+    rank ever exceeds it.  ``width`` < 160 gathers only the first ``width`` bytes of each record
+    (BTLE records use at most 24 + 42 bytes; the rest is zero by construction).
+    """
+
+    def __init__(self, device=None, group=None, width: int = REC):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.on_gpu = self.backend == "nccl"
+        self.device = device if self.on_gpu else torch.device("cpu")
+        self.width = int(width)
+        assert 24 < self.width <= REC and self.width % 8 == 0
+        self.cap = 0
+        self.slots = []
+        self.inflight = []
+        self.stream = torch.cuda.Stream(device=device) if self.on_gpu else None
+        self.dtype = np.dtype([("sample_index", "<u8"), ("proto", "<u4"), ("channel", "<u2"),
+                               ("len", "<u2"), ("crc_ok", "u1"), ("lqi", "u1"), ("pdu_type", "u1"),
+                               ("flags", "u1"), ("aux", "<u4"), ("bytes", "u1", (self.width - 24,))])
+
+    def _agree_cap(self, n: int):
+        t = self.torch.tensor([n], dtype=self.torch.int64, device=self.device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.cap = int(t.item()) + int(t.item()) // 4 + 256
+        torch = self.torch
+        self.slots = []
+        for _ in range(2):
+            send = torch.zeros((self.cap + 1) * self.width, dtype=torch.uint8, device=self.device)
+            recv = torch.zeros(self.world * (self.cap + 1) * self.width, dtype=torch.uint8,
+                               device=self.device)
+            host = torch.zeros(recv.shape, dtype=torch.uint8,
+                               pin_memory=self.on_gpu) if self.rank == 0 else None
+            ev = torch.cuda.Event() if self.on_gpu else None
+            self.slots.append(dict(send=send, recv=recv, host=host, ev=ev))
+        self.next = 0
+
+    def start(self, rec: np.ndarray) -> None:
+        torch = self.torch
+        n = int(rec.size)
+        while len(self.inflight) >= 2:
+            raise RuntimeError("two gathers in flight: finish() one first")
+        if n > self.cap or not self.slots:
+            # (re)negotiate the slot count; collective and synchronous, so drain first
+            assert not self.inflight, "capacity change with gathers in flight"
+            self._agree_cap(n)
+        slot = self.slots[self.next]
+        self.next ^= 1
+        hdr = np.zeros(self.width, dtype=np.uint8)
+        hdr[:8] = np.frombuffer(np.uint64(n).tobytes(), dtype=np.uint8)
+        src = np.ascontiguousarray(rec).view(np.uint8).reshape(n, REC)[:, :self.width] if n else None
+        ctx = torch.cuda.stream(self.stream) if self.on_gpu else _null_ctx()
+        if self.on_gpu:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with ctx:
+            send = slot["send"]
+            send[:self.width].copy_(torch.from_numpy(hdr), non_blocking=True)
+            if n:
+                view = send[self.width:(n + 1) * self.width].view(n, self.width)
+                view.copy_(torch.from_numpy(src), non_blocking=True)
+            if self.world > 1:
+                self.dist.all_gather_into_tensor(slot["recv"], send, group=self.group)
+            else:
+                slot["recv"].copy_(send)
+            if self.rank == 0:
+                slot["host"].copy_(slot["recv"], non_blocking=True)
+            if self.on_gpu:
+                slot["ev"].record(self.stream)
+        self.inflight.append(slot)
+
+    def finish(self) -> Optional[np.ndarray]:
+        if not self.inflight:
+            return None
+        slot = self.inflight.pop(0)
+        if self.on_gpu:
+            slot["ev"].synchronize()
+        if self.rank != 0:
+            return None
+        host = slot["host"].numpy().reshape(self.world, (self.cap + 1) * self.width)
+        parts = []
+        for r in range(self.world):
+            n = int(np.frombuffer(host[r, :8].tobytes(), dtype="<u8")[0])
+            parts.append(host[r, self.width:(n + 1) * self.width].reshape(n, self.width))
+        return np.concatenate(parts).reshape(-1).view(self.dtype)
+
+
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

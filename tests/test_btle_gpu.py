@@ -145,3 +145,39 @@ def test_pipelined_submit_collect_matches_sync(oracle):
         # a view stays valid across one more submit
         rx.submit(segs[1][1]); v = rx.collect(copy=False); keep = v.copy()
         rx.submit(segs[2][1]); assert np.array_equal(v["bytes"], keep["bytes"]); rx.collect()
+
+
+def test_async_record_gather_over_rccl_world1():
+    """The nccl(=RCCL) code path of the pipelined gather on one GPU (world_size 1)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from snout_amd import dist as sdist
+    from snout_amd.rx import SnoutRx
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        x, _ = synth.btle_capture(1 << 20, seed=51, mean_gap=5000.0)
+        t = torch.from_numpy(x.view(np.float32)).cuda()
+        g = sdist.AsyncRecordGather(torch.device("cuda", 0), width=80)
+        with SnoutRx(proto=0, channel=37) as rx:
+            want = rx.process(t)
+            outs = []
+            for i in range(4):
+                rx.submit(t)
+                if i:
+                    pk = rx.collect(copy=False)
+                    if len(g.inflight) == 2:
+                        outs.append(g.finish())
+                    g.start(pk)
+            g.start(rx.collect(copy=False)) if len(g.inflight) < 2 else None
+            while g.inflight:
+                outs.append(g.finish())
+        assert len(outs) >= 3
+        for o in outs:
+            assert o.dtype.itemsize == 80 and len(o) == len(want)
+            assert np.array_equal(o["sample_index"], want["sample_index"])
+            assert np.array_equal(o["bytes"], want["bytes"][:, :56])
+    finally:
+        dist.destroy_process_group()

@@ -26,7 +26,7 @@ def _recs(keys):
     r = np.zeros(len(keys), dtype=PKT_DTYPE)
     for i, (p, c, s) in enumerate(keys):
         r[i]["proto"], r[i]["channel"], r[i]["sample_index"] = p, c, s
-        r[i]["bytes"][0] = i
+        r[i]["bytes"][0] = i & 0xFF
     return r
 
 
@@ -48,10 +48,25 @@ def _worker(rank, world, port, q):
         rec = _recs([(0, 37, 1000 * rank + i) for i in range(n)])
         out = sdist.gather_records(rec)
         empty = sdist.gather_records(rec[:0] if rank == 1 else rec[:1])
+        # pipelined gatherer: two in flight, compact 80-byte wire records, growing capacity
+        g = sdist.AsyncRecordGather(width=80)
+        seq = []
+        for step in range(4):
+            k = 2 + step + rank if step < 3 else 700
+            r = _recs([(0, 37, 10000 * step + 100 * rank + i) for i in range(k)])
+            if step == 3:
+                while g.inflight:
+                    seq.append(g.finish())
+            elif len(g.inflight) == 2:
+                seq.append(g.finish())
+            g.start(r)
+        while g.inflight:
+            seq.append(g.finish())
         if rank == 0:
-            q.put((out["sample_index"].tolist(), empty["sample_index"].tolist()))
+            q.put((out["sample_index"].tolist(), empty["sample_index"].tolist(),
+                   [s["sample_index"].tolist() for s in seq], int(seq[0].dtype.itemsize)))
         else:
-            assert out is None and empty is None
+            assert out is None and empty is None and all(s is None for s in seq)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -68,9 +83,14 @@ def test_gather_records_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, empty = q.get(timeout=120)
+    got, empty, seq, width = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got == [0, 1, 2, 1000, 1001, 1002, 1003, 1004]
     assert empty == [0]
+    assert width == 80 and len(seq) == 4
+    for step in range(3):
+        want = [10000 * step + i for i in range(2 + step)] + [10000 * step + 100 + i for i in range(3 + step)]
+        assert seq[step] == want
+    assert len(seq[3]) == 1400 and seq[3][0] == 30000 and seq[3][700] == 30100
