@@ -83,101 +83,149 @@ __device__ __forceinline__ void dft5(const cf b[5], cf X[5], const float* __rest
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// wait for the prefetch loads of the next tile and for this tile's output stores at every phase.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int M> struct PfbGeom;
 template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320; };
 template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256; };
 
 template <int M>
 __global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
-    const float2* __restrict__ x, uint64_t n, uint64_t n_out, const float* __restrict__ proto,
-    const float* __restrict__ twM, const float* __restrict__ tw5g, float2* __restrict__ y,
-    uint64_t y_stride)
+    const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles,
+    const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
+    float2* __restrict__ y, uint64_t y_stride, uint32_t ablate)
 {
     using G = PfbGeom<M>;
     constexpr int T = G::T, M1 = G::M1, M2 = G::M2, NT = G::NT, D = M / 2, P = 16;
     constexpr int SPAN = (T - 1) * D + M * P;      // input samples one tile needs
     constexpr int ROW = M + 1;                     // padded LDS row, complex
-    __shared__ float2 xs[SPAN];
-    __shared__ float2 us[T * ROW];
-    __shared__ float2 bs[T * ROW];
+    static_assert(SPAN % 2 == 0 && (T * D) % 2 == 0, "16-byte staging needs even sample counts");
+    constexpr int SPAN4 = SPAN / 2;                // the span as 16-byte pairs of samples
+    constexpr int NPRE = (SPAN4 + NT - 1) / NT;    // pairs each thread stages per tile
+    constexpr int XB = SPAN > T * ROW ? SPAN : T * ROW;
+    __shared__ float2 xb[XB];                      // input span, later the twiddled half-transform
+    __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]
     __shared__ float tw_s[2 * M + 10];
+    float2* xs = xb;
+    float2* bs = xb;
 
     const int t = threadIdx.x;
-    const uint64_t m0 = (uint64_t)blockIdx.x * T;
-    const uint64_t in0 = m0 * D;
-
-    // ---- 1. stage input + twiddles
-    for (int i = t; i < SPAN; i += NT) {
-        const uint64_t g = in0 + (uint64_t)i;
-        xs[i] = g < n ? x[g] : make_float2(0.0f, 0.0f);
-    }
     for (int i = t; i < 2 * M; i += NT) tw_s[i] = twM[i];
     if (t < 10) tw_s[2 * M + t] = tw5g[t];
-
-    // ---- 2. FIR: thread <-> (r, e, g); outputs m = e + 2 (8g + i), i = 0..7
+    // FIR role of this thread: (branch r, output parity e, group grp); taps live in registers
     const int r = t % M, e = (t / M) & 1, grp = t / (2 * M);
     float h[P];
 #pragma unroll
     for (int p = 0; p < P; p++) h[p] = proto[r + p * M];
-    __syncthreads();
-    {
-        const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8g]
-        float2 w[8 + P - 1];
+
+    // The workgroup walks tiles blockIdx.x, +gridDim.x, ...; the input of the NEXT tile is fetched
+    // into registers while the current one is computed.
+    float4 pre[NPRE];
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    auto fetch = [&](uint32_t tile) {
+        const uint64_t in0 = (uint64_t)tile * T * D;            // even -> 16-byte aligned
 #pragma unroll
-        for (int q = 0; q < 8 + P - 1; q++) w[q] = xs[base + q * M];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            float ar = 0.0f, ai = 0.0f;
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                ar = __builtin_fmaf(h[p], w[i + p].x, ar);
-                ai = __builtin_fmaf(h[p], w[i + p].y, ai);
+        for (int k = 0; k < NPRE; k++) {
+            const int i = t + k * NT;
+            const uint64_t g = in0 + 2ull * (uint64_t)i;         // first sample of the pair
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i < SPAN4) {
+                if (g + 1 < n) v = x4[g >> 1];
+                else if (g < n) { const float2 a = x[g]; v.x = a.x; v.y = a.y; }
             }
-            const int m = e + 2 * (8 * grp + i);
-            us[m * ROW + r] = make_float2(ar, ai);
+            pre[k] = v;
         }
-    }
-    __syncthreads();
+    };
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t m0 = (uint64_t)tile * T;
+        // ---- 1. stage the prefetched input span
+#pragma unroll
+        for (int k = 0; k < NPRE; k++) {
+            const int i = t + k * NT;
+            if (i < SPAN4) reinterpret_cast<float4*>(xs)[i] = pre[k];
+        }
+        lds_barrier();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
 
-    // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}
-    for (int it = t; it < T * M2; it += NT) {
-        const int m = it % T, n2 = it / T;
-        cf a[M1], A[M1];
+        // ---- 2. FIR: outputs m = e + 2 (8 grp + i), i = 0..7 of branch r: a sliding dot product
+        if (!(ablate & 1u)) {
+            const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
+            float2 w[8 + P - 1];
 #pragma unroll
-        for (int n1 = 0; n1 < M1; n1++) {
-            const float2 v = us[m * ROW + M2 * n1 + n2];
-            a[n1] = cf{v.x, v.y};
-        }
-        if constexpr (M1 == 8) dft8(a, A); else dft4(a, A);
+            for (int q = 0; q < 8 + P - 1; q++) w[q] = xs[base + q * M];
 #pragma unroll
-        for (int k1 = 0; k1 < M1; k1++) {
-            const int j = (n2 * k1) % M;
-            const cf v = j ? cmul_tw(A[k1], tw_s[2 * j], tw_s[2 * j + 1]) : A[k1];
-            bs[m * ROW + n2 * M1 + k1] = make_float2(v.re, v.im);
-        }
-    }
-    __syncthreads();
-
-    // ---- 3b. M2-point DFTs over n2 for every (m, k1); y_k[m] = (-1)^{km} X[k]
-    for (int it = t; it < T * M1; it += NT) {
-        const int m = it % T, k1 = it / T;
-        cf b[M2], Y[M2];
+            for (int i = 0; i < 8; i++) {
+                float ar = 0.0f, ai = 0.0f;
 #pragma unroll
-        for (int n2 = 0; n2 < M2; n2++) {
-            const float2 v = bs[m * ROW + n2 * M1 + k1];
-            b[n2] = cf{v.x, v.y};
-        }
-        if constexpr (M2 == 5) dft5(b, Y, &tw_s[2 * M]); else dft4(b, Y);
-        const uint64_t mg = m0 + (uint64_t)m;
-        if (mg < n_out) {
-#pragma unroll
-            for (int k2 = 0; k2 < M2; k2++) {
-                const int k = k1 + M1 * k2;
-                cf v = Y[k2];
-                if (k & (int)(mg & 1u)) { v.re = -v.re; v.im = -v.im; }
-                y[(uint64_t)k * y_stride + mg] = make_float2(v.re, v.im);
+                for (int p = 0; p < P; p++) {
+                    ar = __builtin_fmaf(h[p], w[i + p].x, ar);
+                    ai = __builtin_fmaf(h[p], w[i + p].y, ai);
+                }
+                const int m = e + 2 * (8 * grp + i);
+                us[m * ROW + r] = make_float2(ar, ai);
             }
         }
+        lds_barrier();        // xs is dead from here: bs reuses its storage
+
+        // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}
+        for (int it = t; it < ((ablate & 2u) ? 0 : T * M2); it += NT) {
+            const int m = it % T, n2 = it / T;
+            cf a[M1], A[M1];
+#pragma unroll
+            for (int n1 = 0; n1 < M1; n1++) {
+                const float2 v = us[m * ROW + M2 * n1 + n2];
+                a[n1] = cf{v.x, v.y};
+            }
+            if constexpr (M1 == 8) dft8(a, A); else dft4(a, A);
+#pragma unroll
+            for (int k1 = 0; k1 < M1; k1++) {
+                const int j = (n2 * k1) % M;
+                const cf v = j ? cmul_tw(A[k1], tw_s[2 * j], tw_s[2 * j + 1]) : A[k1];
+                bs[m * ROW + n2 * M1 + k1] = make_float2(v.re, v.im);
+            }
+        }
+        lds_barrier();
+
+        // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
+        //      A thread owns two consecutive output times so each store is 16 bytes.
+        for (int it = t; it < ((ablate & 4u) ? 0 : (T / 2) * M1); it += NT) {
+            const int mp = it % (T / 2), k1 = it / (T / 2);
+            cf Y0[M2], Y1[M2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                const int m = 2 * mp + h2;
+                cf b[M2];
+#pragma unroll
+                for (int n2 = 0; n2 < M2; n2++) {
+                    const float2 v = bs[m * ROW + n2 * M1 + k1];
+                    b[n2] = cf{v.x, v.y};
+                }
+                if (h2 == 0) { if constexpr (M2 == 5) dft5(b, Y0, &tw_s[2 * M]); else dft4(b, Y0); }
+                else         { if constexpr (M2 == 5) dft5(b, Y1, &tw_s[2 * M]); else dft4(b, Y1); }
+            }
+            const uint64_t mg = m0 + 2ull * (uint64_t)mp;        // even: only the odd time flips
+            if (!(ablate & 8u)) {
+#pragma unroll
+                for (int k2 = 0; k2 < M2; k2++) {
+                    const int k = k1 + M1 * k2;
+                    cf v1 = Y1[k2];
+                    if (k & 1) { v1.re = -v1.re; v1.im = -v1.im; }
+                    float2* dst = &y[(uint64_t)k * y_stride + mg];
+                    if (mg + 1 < n_out) *reinterpret_cast<float4*>(dst) = make_float4(Y0[k2].re, Y0[k2].im, v1.re, v1.im);
+                    else if (mg < n_out) *dst = make_float2(Y0[k2].re, Y0[k2].im);
+                }
+            }
+        }
+        lds_barrier();        // bs (= xs) is overwritten by the next tile's input
     }
 }
 
@@ -189,6 +237,8 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 int PfbCtx::init(uint32_t M_)
 {
     M = M_;
+    if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
+    if (const char* e = getenv("SNOUT_PFB_ABLATE")) ablate = (uint32_t)atoi(e);   // timing experiments only
     if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
     const float* proto = M == 40 ? kPfbProto40 : kPfbProto16;
     const float* tw = M == 40 ? kTw40 : kTw16;
@@ -218,18 +268,22 @@ uint64_t PfbCtx::n_out_for(uint64_t n) const
 int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st)
 {
     n_out = n_out_for(n);
-    y_stride = n_out + 64;
+    y_stride = (n_out + 64 + 1) & ~1ull;      // even: channel rows stay 16-byte aligned
     if (int rc = d_y.ensure(y_stride * M * 8u)) return rc;
     if (n_out == 0) return 0;
     SNOUT_HIP(hipEventRecord(ev_k0, st));
-    if (M == 40)
-        hipLaunchKernelGGL(pfb_channelize<40>, dim3(cdiv(n_out, PfbGeom<40>::T)), dim3(PfbGeom<40>::NT),
-                           0, st, (const float2*)d_iq, n, n_out, d_proto.as<float>(), d_tw.as<float>(),
-                           d_tw5.as<float>(), d_y.as<float2>(), y_stride);
-    else
-        hipLaunchKernelGGL(pfb_channelize<16>, dim3(cdiv(n_out, PfbGeom<16>::T)), dim3(PfbGeom<16>::NT),
-                           0, st, (const float2*)d_iq, n, n_out, d_proto.as<float>(), d_tw.as<float>(),
-                           d_tw5.as<float>(), d_y.as<float2>(), y_stride);
+    // persistent workgroups: 3 per CU (LDS-limited), each walks tiles with a stride of the grid
+    if (M == 40) {
+        const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
+        hipLaunchKernelGGL(pfb_channelize<40>, dim3(std::min(n_tiles, grid_blocks)), dim3(PfbGeom<40>::NT),
+                           0, st, (const float2*)d_iq, n, n_out, n_tiles, d_proto.as<float>(),
+                           d_tw.as<float>(), d_tw5.as<float>(), d_y.as<float2>(), y_stride, ablate);
+    } else {
+        const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
+        hipLaunchKernelGGL(pfb_channelize<16>, dim3(std::min(n_tiles, grid_blocks)), dim3(PfbGeom<16>::NT),
+                           0, st, (const float2*)d_iq, n, n_out, n_tiles, d_proto.as<float>(),
+                           d_tw.as<float>(), d_tw5.as<float>(), d_y.as<float2>(), y_stride, ablate);
+    }
     SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());
     return 0;

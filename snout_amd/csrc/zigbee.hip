@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
 #pragma unroll
             for (uint32_t row = 0; row < 64u; row++) ring[rr + row] = pre[row];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();    // one wave per workgroup: LDS is program-ordered
         fetch_tile(r0 + 64u);       // in flight while this tile is processed
         if (!done) {
             // ---- a5: DC removal, sequential over the new samples of this lane's column
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
             }
             if (hi >= avail && ii + 8u > avail) done = true;      // ran out of samples
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();    // one wave per workgroup: LDS is program-ordered
     }
     if (active) lane_cnt[g] = n_pk;
     if (tap && soft_n) *soft_n = n_chips;
