@@ -69,7 +69,8 @@ typedef struct snout_rx_cfg {
     uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 2048 */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
-    uint32_t reserved[4];
+    uint32_t reserved[4];     /* [0] bit 0: wideband BTLE keeps channel IQ in HBM (unfused; needed for
+                                 the SNOUT_STAGE_CHAN_IQ tap), default is the fused bit slicer    */
 } snout_rx_cfg;
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */

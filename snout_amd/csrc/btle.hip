@@ -570,7 +570,12 @@ int BtleCtx::reserve(uint64_t n)
         set_last_error("segment too large for the tile-sum tables");
         return SNOUT_ERANGE;
     }
-    if (int rc = d_planes.ensure(plane_stride * n_slots * 8u)) return rc;
+    {
+        const void* before = d_planes.p;
+        if (int rc = d_planes.ensure(plane_stride * n_slots * 8u)) return rc;
+        // words never written (tail of the last chunk, padding) must read as zero bits
+        if (d_planes.p != before) SNOUT_HIP(hipMemset(d_planes.p, 0, d_planes.cap));
+    }
     if (int rc = d_chunk_cnt.ensure((lists + kScanTile) * 4u)) return rc;
     if (int rc = d_chunk_hits.ensure(lists * hit_cap * 4u)) return rc;
     if (int rc = d_hit_n.ensure((uint64_t)max_cand * 4u)) return rc;

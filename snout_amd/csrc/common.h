@@ -116,7 +116,9 @@ struct PfbCtx {
     int init(uint32_t M);
     void destroy();
     uint64_t n_out_for(uint64_t n) const;
-    int run(const float* d_iq, uint64_t n, hipStream_t st);
+    // planes16 != null (M = 40): fused BTLE mode, hard bits go straight into the bit planes
+    int run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16 = nullptr,
+            uint64_t plane_stride = 0);
 };
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
@@ -124,6 +126,7 @@ struct ZbCtx {
     uint32_t n_slots = 0, threshold = 10, core = 16384, warmup = 2048;
     uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
+    uint32_t ablate = 0;            // dev: skip stages (wrong results) to price them
     uint64_t d_stride = 0;
     bool overflow = false;
     DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft;

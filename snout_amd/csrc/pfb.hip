@@ -93,37 +93,50 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 template <int M> struct PfbGeom;
-template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320; };
-template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256; };
+template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320, NTF = 384; };
+template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256, NTF = 256; };
 
-template <int M>
-__global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
+// FUSED (BTLE, M = 40): instead of writing 16 B of channel IQ per input sample, the tile keeps its
+// outputs in LDS, computes 4 extra output times as a halo and emits the BTLE hard bits
+//   bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m])
+// of all 40 channels straight into the bit planes the correlator reads (0.25 B per input sample).
+template <int M, bool FUSED>
+__global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_channelize(
     const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
-    float2* __restrict__ y, uint64_t y_stride, uint32_t ablate)
+    float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
+    uint64_t plane_stride, uint32_t ablate)
 {
     using G = PfbGeom<M>;
-    constexpr int T = G::T, M1 = G::M1, M2 = G::M2, NT = G::NT, D = M / 2, P = 16;
-    constexpr int SPAN = (T - 1) * D + M * P;      // input samples one tile needs
+    constexpr int T = G::T, M1 = G::M1, M2 = G::M2, D = M / 2, P = 16;
+    constexpr int NT = FUSED ? G::NTF : G::NT;     // threads in the workgroup
+    constexpr int NFIR = G::NT;                    // threads with a FIR role
+    constexpr int TH = FUSED ? T + 4 : T;          // output times computed per tile (halo for demod)
+    constexpr int SPAN = (TH - 1) * D + M * P;     // input samples one tile needs
     constexpr int ROW = M + 1;                     // padded LDS row, complex
+    constexpr int YROW = TH + 1;                   // fused: channel-major tile, padded
     static_assert(SPAN % 2 == 0 && (T * D) % 2 == 0, "16-byte staging needs even sample counts");
     constexpr int SPAN4 = SPAN / 2;                // the span as 16-byte pairs of samples
     constexpr int NPRE = (SPAN4 + NT - 1) / NT;    // pairs each thread stages per tile
-    constexpr int XB = SPAN > T * ROW ? SPAN : T * ROW;
+    constexpr int XB = SPAN > TH * ROW ? SPAN : TH * ROW;
+    constexpr int UB = (FUSED && M * YROW > TH * ROW) ? M * YROW : TH * ROW;
     __shared__ float2 xb[XB];                      // input span, later the twiddled half-transform
-    __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]
+    __shared__ float2 ub[UB];                      // FIR outputs u_m[r]; fused: later y_k[m]
     __shared__ float tw_s[2 * M + 10];
     float2* xs = xb;
     float2* bs = xb;
+    float2* us = ub;
+    float2* ys = ub;
 
     const int t = threadIdx.x;
     for (int i = t; i < 2 * M; i += NT) tw_s[i] = twM[i];
     if (t < 10) tw_s[2 * M + t] = tw5g[t];
     // FIR role of this thread: (branch r, output parity e, group grp); taps live in registers
     const int r = t % M, e = (t / M) & 1, grp = t / (2 * M);
+    constexpr int NGRP = NFIR / (2 * M);           // groups of 8 outputs per parity
     float h[P];
 #pragma unroll
-    for (int p = 0; p < P; p++) h[p] = proto[r + p * M];
+    for (int p = 0; p < P; p++) h[p] = (t < NFIR) ? proto[r + p * M] : 0.0f;
 
     // The workgroup walks tiles blockIdx.x, +gridDim.x, ...; the input of the NEXT tile is fetched
     // into registers while the current one is computed.
@@ -156,14 +169,18 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
         lds_barrier();
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
 
-        // ---- 2. FIR: outputs m = e + 2 (8 grp + i), i = 0..7 of branch r: a sliding dot product
-        if (!(ablate & 1u)) {
+        // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product.
+        //      Fused: the last group also produces the 2 extra outputs per parity of the halo.
+        if (!(ablate & 1u) && t < NFIR) {
+            constexpr int NI = FUSED ? 10 : 8;
+            const int n_i = (FUSED && grp == NGRP - 1) ? 10 : 8;
             const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
-            float2 w[8 + P - 1];
+            float2 w[NI + P - 1];
 #pragma unroll
-            for (int q = 0; q < 8 + P - 1; q++) w[q] = xs[base + q * M];
+            for (int q = 0; q < NI + P - 1; q++)
+                w[q] = (q < n_i + P - 1) ? xs[base + q * M] : make_float2(0.0f, 0.0f);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < NI; i++) {
                 float ar = 0.0f, ai = 0.0f;
 #pragma unroll
                 for (int p = 0; p < P; p++) {
@@ -171,14 +188,14 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
                     ai = __builtin_fmaf(h[p], w[i + p].y, ai);
                 }
                 const int m = e + 2 * (8 * grp + i);
-                us[m * ROW + r] = make_float2(ar, ai);
+                if (i < n_i) us[m * ROW + r] = make_float2(ar, ai);
             }
         }
         lds_barrier();        // xs is dead from here: bs reuses its storage
 
         // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}
-        for (int it = t; it < ((ablate & 2u) ? 0 : T * M2); it += NT) {
-            const int m = it % T, n2 = it / T;
+        for (int it = t; it < ((ablate & 2u) ? 0 : TH * M2); it += NT) {
+            const int m = it % TH, n2 = it / TH;
             cf a[M1], A[M1];
 #pragma unroll
             for (int n1 = 0; n1 < M1; n1++) {
@@ -193,12 +210,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
                 bs[m * ROW + n2 * M1 + k1] = make_float2(v.re, v.im);
             }
         }
-        lds_barrier();
+        lds_barrier();        // us is dead from here (fused: ys reuses its storage)
 
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
-        //      A thread owns two consecutive output times so each store is 16 bytes.
-        for (int it = t; it < ((ablate & 4u) ? 0 : (T / 2) * M1); it += NT) {
-            const int mp = it % (T / 2), k1 = it / (T / 2);
+        //      A thread owns two consecutive output times so each global store is 16 bytes.
+        for (int it = t; it < ((ablate & 4u) ? 0 : (TH / 2) * M1); it += NT) {
+            const int mp = it % (TH / 2), k1 = it / (TH / 2);
             cf Y0[M2], Y1[M2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++) {
@@ -213,12 +230,15 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
                 else         { if constexpr (M2 == 5) dft5(b, Y1, &tw_s[2 * M]); else dft4(b, Y1); }
             }
             const uint64_t mg = m0 + 2ull * (uint64_t)mp;        // even: only the odd time flips
-            if (!(ablate & 8u)) {
 #pragma unroll
-                for (int k2 = 0; k2 < M2; k2++) {
-                    const int k = k1 + M1 * k2;
-                    cf v1 = Y1[k2];
-                    if (k & 1) { v1.re = -v1.re; v1.im = -v1.im; }
+            for (int k2 = 0; k2 < M2; k2++) {
+                const int k = k1 + M1 * k2;
+                cf v1 = Y1[k2];
+                if (k & 1) { v1.re = -v1.re; v1.im = -v1.im; }
+                if constexpr (FUSED) {
+                    ys[k * YROW + 2 * mp] = make_float2(Y0[k2].re, Y0[k2].im);
+                    ys[k * YROW + 2 * mp + 1] = make_float2(v1.re, v1.im);
+                } else if (!(ablate & 8u)) {
                     float2* dst = &y[(uint64_t)k * y_stride + mg];
                     if (mg + 1 < n_out) *reinterpret_cast<float4*>(dst) = make_float4(Y0[k2].re, Y0[k2].im, v1.re, v1.im);
                     else if (mg < n_out) *dst = make_float2(Y0[k2].re, Y0[k2].im);
@@ -226,6 +246,32 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) void pfb_channelize(
             }
         }
         lds_barrier();        // bs (= xs) is overwritten by the next tile's input
+
+        if constexpr (FUSED) {
+            // ---- 4. hard bits of the tile's T samples of every channel.  A 16-lane group owns
+            //      (channel k, phase j): lane s of it decides symbol s, i.e. sample m = 4 s + j; the
+            //      ballot packs the 16 decisions, one lane stores them as the tile's quarter of the
+            //      64-symbol plane word (planes: [slot k][word g][phase j] u64, bit l = sample 256g+4l+j).
+            const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;          // bits exist for m < n_out-4
+            const uint32_t lane = (uint32_t)t & 63u, sym = lane & 15u, q = lane >> 4;
+            const uint64_t g = m0 >> 8;                                  // plane word index
+            const uint32_t quarter = (uint32_t)((m0 & 255u) >> 6);       // which 16 symbols of it
+            for (int grp0 = (t >> 6) * 4; grp0 < M * 4; grp0 += (NT / 64) * 4) {
+                const int gi = grp0 + (int)q;                             // (k, j) group of this lane
+                const int k = gi >> 2, j = gi & 3;
+                const int m = 4 * (int)sym + j;
+                bool bit = false;
+                if (gi < M * 4) {
+                    const float2 a = ys[k * YROW + m], b4 = ys[k * YROW + m + 4];
+                    bit = ((a.x * b4.y) > (b4.x * a.y)) && (m0 + (uint64_t)m < nbits);
+                }
+                const uint64_t mask = __ballot(bit);
+                if (sym == 0 && gi < M * 4)
+                    planes16[((uint64_t)k * plane_stride + g * 4u + (uint32_t)j) * 4u + quarter] =
+                        (uint16_t)(mask >> (16u * q));
+            }
+            lds_barrier();    // ys (= us) is overwritten by the next tile's FIR
+        }
     }
 }
 
@@ -265,24 +311,32 @@ uint64_t PfbCtx::n_out_for(uint64_t n) const
     return n >= L ? (n - L) / D + 1u : 0u;
 }
 
-int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st)
+int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride)
 {
     n_out = n_out_for(n);
     y_stride = (n_out + 64 + 1) & ~1ull;      // even: channel rows stay 16-byte aligned
-    if (int rc = d_y.ensure(y_stride * M * 8u)) return rc;
+    if (!planes16) { if (int rc = d_y.ensure(y_stride * M * 8u)) return rc; }
     if (n_out == 0) return 0;
     SNOUT_HIP(hipEventRecord(ev_k0, st));
     // persistent workgroups: 3 per CU (LDS-limited), each walks tiles with a stride of the grid
     if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
-        hipLaunchKernelGGL(pfb_channelize<40>, dim3(std::min(n_tiles, grid_blocks)), dim3(PfbGeom<40>::NT),
-                           0, st, (const float2*)d_iq, n, n_out, n_tiles, d_proto.as<float>(),
-                           d_tw.as<float>(), d_tw5.as<float>(), d_y.as<float2>(), y_stride, ablate);
+        if (planes16)
+            hipLaunchKernelGGL((pfb_channelize<40, true>), dim3(std::min(n_tiles, grid_blocks)),
+                               dim3(PfbGeom<40>::NTF), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
+                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
+                               (float2*)nullptr, (uint64_t)0, planes16, plane_stride, ablate);
+        else
+            hipLaunchKernelGGL((pfb_channelize<40, false>), dim3(std::min(n_tiles, grid_blocks)),
+                               dim3(PfbGeom<40>::NT), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
+                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
+                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, ablate);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
-        hipLaunchKernelGGL(pfb_channelize<16>, dim3(std::min(n_tiles, grid_blocks)), dim3(PfbGeom<16>::NT),
-                           0, st, (const float2*)d_iq, n, n_out, n_tiles, d_proto.as<float>(),
-                           d_tw.as<float>(), d_tw5.as<float>(), d_y.as<float2>(), y_stride, ablate);
+        hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(std::min(n_tiles, grid_blocks)),
+                           dim3(PfbGeom<16>::NT), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
+                           d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
+                           d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, ablate);
     }
     SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());

@@ -118,10 +118,13 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     const float* ch_iq = s.iq;
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
     SNOUT_HIP(hipEventRecord(s.ev_t0, st));
+    const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.reserved[0] & 1u);
     if (h->wide) {
         n_ch = h->pfb.n_out_for(s.n_in);
+        if (fused) { if (int rc = h->btle.reserve(n_ch)) return rc; }
         SNOUT_HIP(hipEventRecord(s.ev_k0, st));
-        if (int rc = h->pfb.run(s.iq, s.n_in, st)) return rc;
+        if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? h->btle.d_planes.as<uint16_t>() : nullptr,
+                                h->btle.plane_stride)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         ch_iq = h->pfb.d_y.as<float>();
         ch_stride = h->pfb.y_stride;
@@ -129,7 +132,11 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     if (h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = h->btle;
         if (int rc = b.reserve(n_ch)) return rc;
-        if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s)) return rc;
+        if (fused) {
+            if (int rc = b.launch_corr_planes(n_ch, st)) return rc;       // bits are already in the planes
+        } else {
+            if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s)) return rc;
+        }
         if (int rc = b.enqueue_tail(n_ch, s.first_index, st, s)) return rc;
     } else {
         ZbCtx& z = h->zb;

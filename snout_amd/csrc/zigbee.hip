@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
     const uint16_t* __restrict__ slot_channel, uint64_t first_index,
     const float* __restrict__ mmse, snout_pkt* __restrict__ stage, uint32_t K,
     uint32_t* __restrict__ lane_cnt, float* __restrict__ soft_z, float* __restrict__ soft_chips,
-    uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n)
+    uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n, uint32_t ablate)
 {
     __shared__ float ring[kRingRows * kRingStride];
     __shared__ float taps[129 * 8];
@@ -249,9 +249,10 @@ __global__ __launch_bounds__(64) void zb_lanes(
     auto fetch_tile = [&](uint32_t r0) {
 #pragma unroll
         for (uint32_t row = 0; row < 64u; row++) {
-            const uint32_t b_lo = __shfl((uint32_t)base, (int)row);
-            const uint32_t b_hi = __shfl((uint32_t)(base >> 32), (int)row);
-            const uint32_t av = __shfl(done ? 0u : avail, (int)row);
+            // v_readlane with a constant lane -> SGPRs (a __shfl here becomes three ds_bpermute)
+            const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)row);
+            const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), (int)row);
+            const uint32_t av = (uint32_t)__builtin_amdgcn_readlane((int)(done ? 0u : avail), (int)row);
             const uint64_t rb = ((uint64_t)b_hi << 32) | b_lo;
             const uint32_t r = r0 + l;
             pre[row] = r < av ? d[rb + r] : 0.0f;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
         if (!done) {
             // ---- a5: DC removal, sequential over the new samples of this lane's column
             const uint32_t hi = (r0 + 64u) < avail ? (r0 + 64u) : avail;
-            for (uint32_t r = r0; r < hi; r++) {
+            for (uint32_t r = r0; r < ((ablate & 4u) ? r0 : hi); r++) {
                 const uint32_t idx = (r & (kRingRows - 1)) * kRingStride + l;
                 const float x = ring[idx];
                 lp = alpha * (double)x + one_minus * lp;
@@ -285,9 +286,13 @@ __global__ __launch_bounds__(64) void zb_lanes(
                 const int imu = (int)rintf(mu * 128.0f);
                 const float* tp = &taps[imu * 8];
                 float acc = 0.0f;
+                if (!(ablate & 2u)) {
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
+                    for (int k = 0; k < 8; k++)
+                        acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
+                } else {
+                    acc = ring[((ii + 3u) & (kRingRows - 1)) * kRingStride + l];
+                }
                 const float o = acc;
                 if (tap && n_chips < soft_cap) soft_chips[n_chips] = o;
                 n_chips++;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
 
                 const bool was_idle = (s.state == 0 && s.preamble_cnt == 0);
                 uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
-                const bool fin = sink_chip(s, o, at, th, pb);
+                const bool fin = (ablate & 1u) ? false : sink_chip(s, o, at, th, pb);
                 if (was_idle && s.preamble_cnt == 1 && s.trigger >= rel_core_end) { done = true; break; }
                 if (fin) {
                     if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
@@ -416,6 +421,7 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
                 uint32_t warmup_)
 {
     n_slots = n_slots_;
+    if (const char* e = getenv("SNOUT_ZB_ABLATE")) ablate = (uint32_t)atoi(e);   // timing experiments only
     threshold = threshold_;
     core = core_;
     warmup = warmup_;
@@ -459,7 +465,7 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int so
                        d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
                        d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), sz, sc,
-                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
+                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn, ablate);
     SNOUT_HIP(hipGetLastError());
     return 0;
 }

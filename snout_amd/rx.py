@@ -29,13 +29,14 @@ class SnoutRx:
     def __init__(self, proto: int = PROTO_BTLE, channel: int = 37, n_channels: int = 1,
                  access_addr: int = 0, crc_init: int = 0, chip_threshold: int = 0,
                  taps_per_branch: int = 0, zb_core: int = 0, zb_warmup: int = 0,
-                 max_hits: int = 0, device: int = -1):
+                 max_hits: int = 0, device: int = -1, keep_channel_iq: bool = False):
         self._lib = _ffi.load()
         cfg = _ffi.RxCfg(abi_version=_ffi.ABI_VERSION, proto=proto, n_channels=n_channels,
                          taps_per_branch=taps_per_branch, channel=channel,
                          access_addr=access_addr, crc_init=crc_init,
                          chip_threshold=chip_threshold, zb_core=zb_core, zb_warmup=zb_warmup,
                          max_hits=max_hits, device=device)
+        cfg.reserved[0] = 1 if keep_channel_iq else 0      # unfused wideband BTLE (CHAN_IQ tap)
         self._h = C.c_void_p()
         _ffi.check(self._lib.snout_rx_create(C.byref(cfg), C.byref(self._h)))
         self.proto = proto

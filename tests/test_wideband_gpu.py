@@ -23,7 +23,7 @@ def test_channelizer_bit_exact(oracle, M, proto, n):
     rng = np.random.default_rng(n)
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
     want = oracle.pfb(x, M)
-    with SnoutRx(proto=proto, n_channels=M) as rx:
+    with SnoutRx(proto=proto, n_channels=M, keep_channel_iq=True) as rx:
         rx.process(x)
         for slot in (0, 1, M // 2, M - 1):
             got = rx.soft(STAGE_CHAN_IQ, slot).view(np.complex64)
@@ -42,16 +42,39 @@ def test_wideband_btle_matches_oracle(oracle):
     from snout_amd.rx import SnoutRx
     x, truth = synth.wideband_capture(0, 40 * 30000, seed=3, bins=[0, 1, 7, 19, 20, 21, 33, 39],
                                       mean_gap=5000.0)
-    with SnoutRx(proto=0, n_channels=40) as rx:
-        got = rx.process(x, first_sample_index=777)
     want = oracle.wideband_segment(x, 0, first_sample_index=777)
-    _same_packets(got, want)
+    for keep in (False, True):      # fused bit slicer (default) and the unfused channel-IQ path
+        with SnoutRx(proto=0, n_channels=40, keep_channel_iq=keep) as rx:
+            got = rx.process(x, first_sample_index=777)
+            _same_packets(got, want)
+            if not keep:
+                # the fused planes hold exactly the oracle's hard bits of every channel
+                from snout_amd._ffi import STAGE_BTLE_BITS
+                y = oracle.pfb(x, 40)
+                for slot in (0, 7, 20, 39):
+                    bits = rx.soft(STAGE_BTLE_BITS, slot).astype(np.uint8)
+                    assert np.array_equal(bits, oracle.btle_bits(y[slot]))
     ok = {(int(p["channel"]), bytes(p["bytes"][:p["len"] - 3])) for p in got if p["crc_ok"]}
     found = sum((t.channel, t.payload) in ok for t in truth)
     assert found >= 0.95 * len(truth) and len(truth) > 20
     # records are ordered by (bin, sample_index)
     chans = {int(c) for c in got["channel"]}
     assert chans >= {t.channel for t in truth}
+
+
+@pytest.mark.parametrize("n", [640 + 20 * 3, 640 + 20 * 63, 640 + 20 * 64, 640 + 20 * 200 + 7])
+def test_fused_btle_edges(oracle, n):
+    from snout_amd.rx import SnoutRx
+    from snout_amd._ffi import STAGE_BTLE_BITS
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    y = oracle.pfb(x, 40)
+    with SnoutRx(proto=0, n_channels=40) as rx:
+        got = rx.process(x)
+        _same_packets(got, oracle.wideband_segment(x, 0))
+        if y.shape[1] >= 5:
+            for slot in (0, 39):
+                assert np.array_equal(rx.soft(STAGE_BTLE_BITS, slot).astype(np.uint8), oracle.btle_bits(y[slot]))
 
 
 def test_wideband_zigbee_matches_oracle(oracle):
