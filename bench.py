@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--samples", type=float, default=1e9, help="complex samples per GPU per step")
     ap.add_argument("--cpu-samples", type=float, default=2.5e8)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sync", action="store_true",
+                    help="one segment at a time (no submit/collect pipelining); for profiling")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +128,11 @@ def main():
 
     def run_steps(k):
         last = None
+        if args.sync:
+            for i in range(k):
+                rx.submit(x, first_sample_index=rank * n)
+                last = finish_one()
+            return last
         for i in range(k):
             rx.submit(x, first_sample_index=rank * n)
             if i:
@@ -200,7 +207,9 @@ def main():
                        "samples_per_gpu": n, "packets_per_gpu": int(len(local)),
                        "decoded_pkts_per_s": len(local) * world * args.steps / dt,
                        "sharding": "segments per rank, RCCL gather of 160-B records" if world > 1
-                                   else "single segment"},
+                                   else "single segment",
+                       "stepping": "one segment at a time" if args.sync else
+                                   "pipelined: record D2H of step i overlaps step i+1"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
