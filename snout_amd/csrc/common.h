@@ -129,7 +129,7 @@ struct ZbCtx {
     uint32_t ablate = 0;            // dev: skip stages (wrong results) to price them
     uint64_t d_stride = 0;
     bool overflow = false;
-    DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft;
+    DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft, d_saves;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
              uint32_t warmup);

@@ -110,11 +110,15 @@ __device__ __forceinline__ uint32_t chip_dist(uint32_t shift, uint32_t word)
 
 __device__ __forceinline__ int decode_chips(SinkState& s, uint32_t th)
 {
+    // words 8..15 are the 30-bit complements of words 0..7 (under the mask): dist = 30 - dist
+    uint32_t dlo[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) dlo[i] = chip_dist(s.shift, kChipMap[i]);
     int best = 0xFF;
     uint32_t min_t = 33;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const uint32_t t = chip_dist(s.shift, kChipMap[i]);
+        const uint32_t t = i < 8 ? dlo[i] : 30u - dlo[i - 8];
         if (t < min_t) { best = i; min_t = t; }
     }
     if (min_t < th) {
@@ -204,30 +208,57 @@ __device__ __forceinline__ bool sink_chip(SinkState& s, float chip, uint32_t at,
     return false;
 }
 
+// Continuation of a lane that reached the end of its core inside a frame it owns.
+struct ZbLaneSave {
+    double lp;
+    float mu, omega, last;
+    uint32_t g, ii, znext, n_pk, n_chips;
+    SinkState s;
+    float zhist[16];        // z[znext-16 .. znext)
+};
+
+// Two passes.  RESUME = false: every lane runs from its warm-up start to the end of its core; a
+// lane that is inside a frame it owns at that point saves its loop state and stops, so no wave is
+// held back by its longest frame.  RESUME = true: the saved lanes (compacted, dense waves) finish
+// their frames.  Both passes perform exactly the operations of the single sequential lane.
+template <bool RESUME>
 __global__ __launch_bounds__(64) void zb_lanes(
     const float* __restrict__ d, uint64_t n, uint64_t d_stride, uint32_t lanes_per_slot,
     uint32_t total_lanes, uint32_t core, uint32_t warmup, uint32_t th,
     const uint16_t* __restrict__ slot_channel, uint64_t first_index,
     const float* __restrict__ mmse, snout_pkt* __restrict__ stage, uint32_t K,
-    uint32_t* __restrict__ lane_cnt, float* __restrict__ soft_z, float* __restrict__ soft_chips,
+    uint32_t* __restrict__ lane_cnt, ZbLaneSave* __restrict__ saves, uint32_t* __restrict__ n_saves,
+    float* __restrict__ soft_z, float* __restrict__ soft_chips,
     uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n, uint32_t ablate)
 {
     __shared__ float ring[kRingRows * kRingStride];
-    __shared__ float taps[129 * 8];
+    __shared__ __attribute__((aligned(16))) float taps[129 * 8];
     const uint32_t l = threadIdx.x;
     for (uint32_t i = l; i < 129u * 8u; i += 64u) taps[i] = mmse[i];
-    const uint32_t g = blockIdx.x * 64u + l;
-    const bool active = g < total_lanes;
+    const uint32_t job = blockIdx.x * 64u + l;
+    uint32_t n_jobs = total_lanes;
+    if constexpr (RESUME) {
+        n_jobs = *n_saves;
+        if (blockIdx.x * 64u >= n_jobs) return;          // whole wave beyond the job list
+    }
+    const bool active = job < n_jobs;
+    ZbLaneSave sv;
+    if constexpr (RESUME) { if (active) sv = saves[job]; }
+    const uint32_t g = RESUME ? (active ? sv.g : 0u) : job;
     const uint32_t slot = active ? g / lanes_per_slot : 0u;
     const uint32_t li = active ? g % lanes_per_slot : 0u;
     const uint64_t core_start = (uint64_t)li * core;
     const uint64_t s0 = core_start > warmup ? core_start - warmup : 0ull;
-    // lane-relative coordinates from here on (r = t - s0)
+    // lane-relative coordinates (r = t - s0); a resumed lane shifts its origin to 64 samples before
+    // the first sample it still has to filter, so every lane of the wave starts at tile 0
+    const uint32_t origin = RESUME ? (active ? sv.znext - 64u : 0u) : 0u;
     const uint32_t rel_core_start = (uint32_t)(core_start - s0);
-    const uint32_t rel_core_end = rel_core_start + core;
-    const uint64_t avail64 = active && n > s0 ? n - s0 : 0ull;
-    const uint32_t avail = avail64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)avail64;
-    const uint64_t base = (uint64_t)slot * d_stride + s0;     // offset of this lane's r = 0 in d
+    const uint32_t rel_core_end = rel_core_start + core;            // in unshifted coordinates
+    const uint64_t avail64 = active && n > s0 + origin ? n - s0 - origin : 0ull;
+    // a frame that starts before the core end is over within 17 024 + a few samples
+    const uint64_t lane_max = (uint64_t)rel_core_end + 20000u - origin;
+    const uint32_t avail = (uint32_t)(avail64 < lane_max ? avail64 : lane_max);
+    const uint64_t base = (uint64_t)slot * d_stride + s0 + origin;  // offset of r = 0 in d
     __syncthreads();
 
     const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
@@ -239,23 +270,32 @@ __global__ __launch_bounds__(64) void zb_lanes(
     enter_search(s);
     s.byte_index = s.packetlen = s.packetlen_cnt = s.payload_cnt = 0;
     s.lqi = s.lqi_cnt = 0; s.trigger = 0; s.c0 = s.c1 = s.c2 = 0; s.b_prev = s.b_last = 0;
-    uint32_t ii = 0;            // window start, lane-relative
+    uint32_t ii = 0;            // window start
+    uint32_t znext = 0;         // first sample not yet through the IIR
     uint32_t n_pk = 0, n_chips = 0;
+    if constexpr (RESUME) {
+        if (active) {
+            lp = sv.lp; mu = sv.mu; omega = sv.omega; last = sv.last; s = sv.s;
+            ii = sv.ii - origin; znext = 64u; n_pk = sv.n_pk; n_chips = sv.n_chips;
+        }
+    }
     bool done = !active || avail < 8u;
     const bool tap = active && g == soft_lane && soft_chips != nullptr;
 
     // Tile t+1 is fetched into registers (one value per row) while tile t is consumed from LDS.
+    // Row = lane whose samples are loaded: its base and length come from v_readlane (SGPRs) and
+    // form a buffer descriptor, so reads past the lane's end return 0 without a branch.
     float pre[64];
     auto fetch_tile = [&](uint32_t r0) {
+        const uint32_t voff = (r0 + l) * 4u;
 #pragma unroll
         for (uint32_t row = 0; row < 64u; row++) {
-            // v_readlane with a constant lane -> SGPRs (a __shfl here becomes three ds_bpermute)
             const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)row);
             const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), (int)row);
             const uint32_t av = (uint32_t)__builtin_amdgcn_readlane((int)(done ? 0u : avail), (int)row);
-            const uint64_t rb = ((uint64_t)b_hi << 32) | b_lo;
-            const uint32_t r = r0 + l;
-            pre[row] = r < av ? d[rb + r] : 0.0f;
+            const float* rp = d + (((uint64_t)b_hi << 32) | b_lo);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rp, 0, (int)(av * 4u), 0x00020000);
+            pre[row] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
         }
     };
     fetch_tile(0u);
@@ -269,24 +309,42 @@ __global__ __launch_bounds__(64) void zb_lanes(
             for (uint32_t row = 0; row < 64u; row++) ring[rr + row] = pre[row];
         }
         __builtin_amdgcn_wave_barrier();    // one wave per workgroup: LDS is program-ordered
-        fetch_tile(r0 + 64u);       // in flight while this tile is processed
-        if (!done) {
-            // ---- a5: DC removal, sequential over the new samples of this lane's column
-            const uint32_t hi = (r0 + 64u) < avail ? (r0 + 64u) : avail;
-            for (uint32_t r = r0; r < ((ablate & 4u) ? r0 : hi); r++) {
-                const uint32_t idx = (r & (kRingRows - 1)) * kRingStride + l;
-                const float x = ring[idx];
-                lp = alpha * (double)x + one_minus * lp;
-                const float z = x - (float)lp;
-                ring[idx] = z;
-                if (tap && soft_z && r < soft_cap) soft_z[r] = z;
+        fetch_tile(r0 + 64u);               // in flight while this tile is processed
+        if constexpr (RESUME) {
+            if (tile == 0 && active) {      // the 16 filtered samples before znext
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; k++) ring[((48u + k) & (kRingRows - 1)) * kRingStride + l] = sv.zhist[k];
             }
-            // ---- a6 + a7 while the 8-tap window is filled
+        }
+        const uint32_t staged = r0 + 64u;
+        const uint32_t hi = staged < avail ? staged : avail;
+        if (!done) {
             while (ii + 8u <= hi) {
+                // ---- a5: DC removal, lazily, 8 samples at a time (sequential fp64 recurrence)
+                if (znext < ii + 8u) {
+                    if (znext + 8u > staged) break;             // next tile needed
+                    if (!(ablate & 4u)) {
+                        float xv[8];
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++) xv[k] = ring[((znext + k) & (kRingRows - 1)) * kRingStride + l];
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++) {
+                            lp = alpha * (double)xv[k] + one_minus * lp;
+                            const float zz = xv[k] - (float)lp;
+                            ring[((znext + k) & (kRingRows - 1)) * kRingStride + l] = zz;
+                            if (tap && soft_z && znext + k + origin < soft_cap) soft_z[znext + k + origin] = zz;
+                        }
+                    }
+                    znext += 8u;
+                    continue;
+                }
+                // ---- a6: Mueller & Mueller step with the 8-tap MMSE interpolator
                 const int imu = (int)rintf(mu * 128.0f);
-                const float* tp = &taps[imu * 8];
                 float acc = 0.0f;
                 if (!(ablate & 2u)) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(&taps[imu * 8]);
+                    const float4 t1 = *reinterpret_cast<const float4*>(&taps[imu * 8 + 4]);
+                    const float tp[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
                     for (int k = 0; k < 8; k++)
                         acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
@@ -306,10 +364,11 @@ __global__ __launch_bounds__(64) void zb_lanes(
                 }
                 mu = mu + omega + gain_mu * mm;
                 const float fl = floorf(mu);
-                const uint32_t at = ii;
-                ii += fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // fl is 1..3 for finite input
+                const uint32_t at = ii + origin;                // unshifted lane-relative index
+                ii += fl >= 1.0f ? (uint32_t)(int)fl : 1u;      // fl is 1..3 for finite input
                 mu = mu - fl;
 
+                // ---- a7: packet sink
                 const bool was_idle = (s.state == 0 && s.preamble_cnt == 0);
                 uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
                 const bool fin = (ablate & 1u) ? false : sink_chip(s, o, at, th, pb);
@@ -337,7 +396,26 @@ __global__ __launch_bounds__(64) void zb_lanes(
                     }
                     enter_search(s);
                 }
-                if (s.state == 0 && s.preamble_cnt == 0 && ii >= rel_core_end) { done = true; break; }
+                if (ii + origin >= rel_core_end) {
+                    if (s.state == 0 && s.preamble_cnt == 0) { done = true; break; }
+                    if constexpr (!RESUME) {
+                        // inside a frame at the end of the core: hand it to the second pass if this
+                        // lane owns it, drop it otherwise (it is never reported and the lane would
+                        // stop right after it)
+                        if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
+                            ZbLaneSave o2;
+                            o2.lp = lp; o2.mu = mu; o2.omega = omega; o2.last = last;
+                            o2.g = g; o2.ii = ii; o2.znext = znext; o2.n_pk = n_pk; o2.n_chips = n_chips;
+                            o2.s = s;
+#pragma unroll
+                            for (uint32_t k = 0; k < 16u; k++)
+                                o2.zhist[k] = ring[((znext - 16u + k) & (kRingRows - 1)) * kRingStride + l];
+                            saves[atomicAdd(n_saves, 1u)] = o2;
+                        }
+                        done = true;
+                        break;
+                    }
+                }
             }
             if (hi >= avail && ii + 8u > avail) done = true;      // ran out of samples
         }
@@ -439,7 +517,7 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
 void ZbCtx::destroy()
 {
     d_atan.release(); d_mmse.release(); d_slot_channel.release();
-    d_d.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
+    d_d.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release(); d_saves.release();
 }
 
 int ZbCtx::reserve(uint64_t n)
@@ -453,6 +531,7 @@ int ZbCtx::reserve(uint64_t n)
     if (int rc = d_lane_cnt.ensure(((uint64_t)total_lanes + 1024u) * 4u)) return rc;
     max_out = total_lanes * pkts_per_lane;
     if (int rc = d_soft.ensure(((uint64_t)kSoftCap * 2u + 16u) * 4u)) return rc;
+    if (int rc = d_saves.ensure((uint64_t)total_lanes * sizeof(ZbLaneSave))) return rc;
     return 0;
 }
 
@@ -461,10 +540,21 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int so
     float* sz = soft_lane >= 0 ? d_soft.as<float>() : nullptr;
     float* sc = soft_lane >= 0 ? d_soft.as<float>() + kSoftCap : nullptr;
     uint32_t* sn = soft_lane >= 0 ? (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap) : nullptr;
-    hipLaunchKernelGGL(zb_lanes, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
+    uint32_t* n_saves = (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap) + 4;
+    SNOUT_HIP(hipMemsetAsync(n_saves, 0, 4, st));
+    hipLaunchKernelGGL(zb_lanes<false>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
                        d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
-                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), sz, sc,
+                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(),
+                       d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
+                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn, ablate);
+    // second pass: the lanes that stopped inside a frame (grid covers the worst case; waves beyond
+    // the saved count exit at once)
+    hipLaunchKernelGGL(zb_lanes<true>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
+                       d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
+                       d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
+                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(),
+                       d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
                        (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn, ablate);
     SNOUT_HIP(hipGetLastError());
     return 0;
