@@ -136,76 +136,66 @@ __device__ __forceinline__ uint32_t crc16_step(uint32_t c, uint32_t byte)
     return c;
 }
 
-// Feed one chip.  Returns true when a frame completed (caller publishes, then enter_search).
-__device__ __forceinline__ bool sink_chip(SinkState& s, float chip, uint32_t at, uint32_t th,
-                                          uint8_t* __restrict__ pkt_bytes)
+// The packet sink, split by what a chip can trigger.
+//  * searching (state 0, preamble_cnt == 0): every chip is tested against symbol 0;
+//  * otherwise chips are only counted until the next symbol boundary (32 chips), where
+//    sink_symbol() does the work.  The lane loop therefore shifts whole runs of chips in at once.
+// Together they are exactly gr-ieee802-15-4's per-chip state machine.
+__device__ __forceinline__ void sink_search_chip(SinkState& s, uint32_t bit, uint32_t at, uint32_t th)
 {
-    s.shift = (s.shift << 1) | (chip > 0.0f ? 1u : 0u);
+    s.shift = (s.shift << 1) | bit;
+    if (chip_dist(s.shift, kChipMap[0]) < th) {
+        s.preamble_cnt = 1;         // chip_cnt stays 0: the boundary is 32 chips after this one
+        s.trigger = at;
+    }
+}
+
+// Called when chip_cnt reached 32 (s.shift holds the symbol's chips).  Returns true when a frame
+// completed (caller publishes, then enter_search).
+__device__ __forceinline__ bool sink_symbol(SinkState& s, uint32_t th, uint8_t* __restrict__ pkt_bytes)
+{
+    s.chip_cnt = 0;
     if (s.state == 0) {
-        if (s.preamble_cnt > 0) s.chip_cnt++;
-        if (s.preamble_cnt == 0) {
-            if (chip_dist(s.shift, kChipMap[0]) < th) {
-                s.preamble_cnt = 1;
-                s.trigger = at;
-            }
-        } else if (s.chip_cnt == 32) {
-            s.chip_cnt = 0;
-            if (s.packet_byte == 0) {
-                if (chip_dist(s.shift, kChipMap[0]) <= th) {
-                    s.preamble_cnt++;
-                } else if (chip_dist(s.shift, kChipMap[7]) <= th) {
-                    s.packet_byte = 7 << 4;
-                } else {
-                    enter_search(s);
-                }
+        if (s.packet_byte == 0) {
+            if (chip_dist(s.shift, kChipMap[0]) <= th) {
+                s.preamble_cnt++;
+            } else if (chip_dist(s.shift, kChipMap[7]) <= th) {
+                s.packet_byte = 7 << 4;
             } else {
-                if (chip_dist(s.shift, kChipMap[10]) <= th) {
-                    s.state = 1; s.packetlen_cnt = 0; s.packet_byte = 0; s.byte_index = 0;
-                    s.lqi = 0; s.lqi_cnt = 0;
-                } else {
-                    enter_search(s);
-                }
+                enter_search(s);
+            }
+        } else {
+            if (chip_dist(s.shift, kChipMap[10]) <= th) {
+                s.state = 1; s.packetlen_cnt = 0; s.packet_byte = 0; s.byte_index = 0;
+                s.lqi = 0; s.lqi_cnt = 0;
+            } else {
+                enter_search(s);
             }
         }
         return false;
     }
+    const int c = decode_chips(s, th);
+    if (c == 0xFF) { enter_search(s); return false; }
+    if (s.byte_index == 0) s.packet_byte = c; else s.packet_byte |= c << 4;
+    s.byte_index++;
+    if ((s.byte_index & 1) != 0) return false;
     if (s.state == 1) {
-        s.chip_cnt++;
-        if (s.chip_cnt == 32) {
-            s.chip_cnt = 0;
-            const int c = decode_chips(s, th);
-            if (c == 0xFF) { enter_search(s); return false; }
-            if (s.byte_index == 0) s.packet_byte = c; else s.packet_byte |= c << 4;
-            s.byte_index++;
-            if ((s.byte_index & 1) == 0) {
-                const int len = s.packet_byte;
-                if (len <= 127) {
-                    s.state = 2; s.packetlen = len; s.payload_cnt = 0; s.packet_byte = 0;
-                    s.byte_index = 0; s.c0 = s.c1 = s.c2 = 0;
-                } else {
-                    enter_search(s);
-                }
-            }
+        const int len = s.packet_byte;
+        if (len <= 127) {
+            s.state = 2; s.packetlen = len; s.payload_cnt = 0; s.packet_byte = 0;
+            s.byte_index = 0; s.c0 = s.c1 = s.c2 = 0;
+        } else {
+            enter_search(s);
         }
         return false;
     }
-    s.chip_cnt = (s.chip_cnt + 1) & 31;
-    if (s.chip_cnt == 0) {
-        const int c = decode_chips(s, th);
-        if (c == 0xFF) { enter_search(s); return false; }
-        if (s.byte_index == 0) s.packet_byte = c; else s.packet_byte |= c << 4;
-        s.byte_index++;
-        if ((s.byte_index & 1) == 0) {
-            if (pkt_bytes) pkt_bytes[s.packetlen_cnt] = (uint8_t)s.packet_byte;
-            s.c2 = s.c1; s.c1 = s.c0; s.c0 = crc16_step(s.c0, (uint32_t)s.packet_byte);
-            s.b_prev = s.b_last; s.b_last = (uint32_t)s.packet_byte;
-            s.packetlen_cnt++;
-            s.payload_cnt++;
-            s.byte_index = 0;
-            if (s.payload_cnt >= s.packetlen) return true;
-        }
-    }
-    return false;
+    if (pkt_bytes) pkt_bytes[s.packetlen_cnt] = (uint8_t)s.packet_byte;
+    s.c2 = s.c1; s.c1 = s.c0; s.c0 = crc16_step(s.c0, (uint32_t)s.packet_byte);
+    s.b_prev = s.b_last; s.b_last = (uint32_t)s.packet_byte;
+    s.packetlen_cnt++;
+    s.payload_cnt++;
+    s.byte_index = 0;
+    return s.payload_cnt >= s.packetlen;
 }
 
 // Continuation of a lane that reached the end of its core inside a frame it owns.
@@ -229,7 +219,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
     const float* __restrict__ mmse, snout_pkt* __restrict__ stage, uint32_t K,
     uint32_t* __restrict__ lane_cnt, ZbLaneSave* __restrict__ saves, uint32_t* __restrict__ n_saves,
     float* __restrict__ soft_z, float* __restrict__ soft_chips,
-    uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n, uint32_t ablate)
+    uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n)
 {
     __shared__ float ring[kRingRows * kRingStride];
     __shared__ __attribute__((aligned(16))) float taps[129 * 8];
@@ -319,41 +309,41 @@ __global__ __launch_bounds__(64) void zb_lanes(
         const uint32_t staged = r0 + 64u;
         const uint32_t hi = staged < avail ? staged : avail;
         if (!done) {
+            // ---- phase 1: a5 + a6 over this tile.  Hard chip decisions and the window advance of
+            //      every chip are packed into three 64-bit words (<= 64 chips per 64-sample tile):
+            //      chip c sits at bit 63-c, so a run of chips is one shift away from the sink's
+            //      shift-register order.
+            uint64_t cw = 0, d_lo = 0, d_hi = 0;
+            uint32_t nc = 0;
+            const uint32_t ii_start = ii;
             while (ii + 8u <= hi) {
-                // ---- a5: DC removal, lazily, 8 samples at a time (sequential fp64 recurrence)
                 if (znext < ii + 8u) {
+                    // a5: DC removal, lazily, 8 samples at a time (sequential fp64 recurrence)
                     if (znext + 8u > staged) break;             // next tile needed
-                    if (!(ablate & 4u)) {
-                        float xv[8];
+                    float xv[8];
 #pragma unroll
-                        for (uint32_t k = 0; k < 8u; k++) xv[k] = ring[((znext + k) & (kRingRows - 1)) * kRingStride + l];
+                    for (uint32_t k = 0; k < 8u; k++) xv[k] = ring[((znext + k) & (kRingRows - 1)) * kRingStride + l];
 #pragma unroll
-                        for (uint32_t k = 0; k < 8u; k++) {
-                            lp = alpha * (double)xv[k] + one_minus * lp;
-                            const float zz = xv[k] - (float)lp;
-                            ring[((znext + k) & (kRingRows - 1)) * kRingStride + l] = zz;
-                            if (tap && soft_z && znext + k + origin < soft_cap) soft_z[znext + k + origin] = zz;
-                        }
+                    for (uint32_t k = 0; k < 8u; k++) {
+                        lp = alpha * (double)xv[k] + one_minus * lp;
+                        const float zz = xv[k] - (float)lp;
+                        ring[((znext + k) & (kRingRows - 1)) * kRingStride + l] = zz;
+                        if (tap && soft_z && znext + k + origin < soft_cap) soft_z[znext + k + origin] = zz;
                     }
                     znext += 8u;
                     continue;
                 }
-                // ---- a6: Mueller & Mueller step with the 8-tap MMSE interpolator
+                // a6: Mueller & Mueller step with the 8-tap MMSE interpolator
                 const int imu = (int)rintf(mu * 128.0f);
+                const float4 t0 = *reinterpret_cast<const float4*>(&taps[imu * 8]);
+                const float4 t1 = *reinterpret_cast<const float4*>(&taps[imu * 8 + 4]);
+                const float tp[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
                 float acc = 0.0f;
-                if (!(ablate & 2u)) {
-                    const float4 t0 = *reinterpret_cast<const float4*>(&taps[imu * 8]);
-                    const float4 t1 = *reinterpret_cast<const float4*>(&taps[imu * 8 + 4]);
-                    const float tp[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
-                } else {
-                    acc = ring[((ii + 3u) & (kRingRows - 1)) * kRingStride + l];
-                }
+                for (int k = 0; k < 8; k++)
+                    acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
                 const float o = acc;
-                if (tap && n_chips < soft_cap) soft_chips[n_chips] = o;
-                n_chips++;
+                if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o;
                 const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
                 last = o;
                 omega = omega + gain_omega * mm;
@@ -364,15 +354,42 @@ __global__ __launch_bounds__(64) void zb_lanes(
                 }
                 mu = mu + omega + gain_mu * mm;
                 const float fl = floorf(mu);
-                const uint32_t at = ii + origin;                // unshifted lane-relative index
-                ii += fl >= 1.0f ? (uint32_t)(int)fl : 1u;      // fl is 1..3 for finite input
+                const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
+                ii += step;
                 mu = mu - fl;
+                const uint64_t pos_bit = 1ull << (63u - nc);
+                if (o > 0.0f) cw |= pos_bit;
+                if ((step - 1u) & 1u) d_lo |= pos_bit;
+                if ((step - 1u) & 2u) d_hi |= pos_bit;
+                nc++;
+            }
 
-                // ---- a7: packet sink
-                const bool was_idle = (s.state == 0 && s.preamble_cnt == 0);
-                uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
-                const bool fin = (ablate & 1u) ? false : sink_chip(s, o, at, th, pb);
-                if (was_idle && s.preamble_cnt == 1 && s.trigger >= rel_core_end) { done = true; break; }
+            // ---- phase 2: a7 over the tile's chips
+            uint32_t c = 0, pos = ii_start;     // pos = window start of chip c (shifted coordinates)
+            while (c < nc) {
+                bool fin = false;
+                if (s.state == 0 && s.preamble_cnt == 0) {
+                    const uint32_t bit = (uint32_t)(cw >> (63u - c)) & 1u;
+                    const uint32_t step = 1u + ((uint32_t)(d_lo >> (63u - c)) & 1u) + 2u * ((uint32_t)(d_hi >> (63u - c)) & 1u);
+                    sink_search_chip(s, bit, pos + origin, th);
+                    pos += step;
+                    c++;
+                    if (s.preamble_cnt == 1 && s.trigger >= rel_core_end) { done = true; break; }  // next lane's
+                } else {
+                    // shift in the chips up to the next symbol boundary (or the end of the tile)
+                    const uint32_t need = 32u - (uint32_t)s.chip_cnt;
+                    const uint32_t take = need < nc - c ? need : nc - c;
+                    const uint64_t fld = (take == 64u) ? ~0ull : ~(~0ull >> take);     // top `take` bits
+                    const uint64_t bits = ((cw << c) & fld) >> (64u - take);
+                    s.shift = take >= 32u ? (uint32_t)bits : ((s.shift << take) | (uint32_t)bits);
+                    pos += take + (uint32_t)__popcll((d_lo << c) & fld) + 2u * (uint32_t)__popcll((d_hi << c) & fld);
+                    c += take;
+                    s.chip_cnt += (int)take;
+                    if (s.chip_cnt == 32) {
+                        uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
+                        fin = sink_symbol(s, th, pb);
+                    }
+                }
                 if (fin) {
                     if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
                         if (n_pk < K) {
@@ -396,26 +413,24 @@ __global__ __launch_bounds__(64) void zb_lanes(
                     }
                     enter_search(s);
                 }
-                if (ii + origin >= rel_core_end) {
-                    if (s.state == 0 && s.preamble_cnt == 0) { done = true; break; }
-                    if constexpr (!RESUME) {
-                        // inside a frame at the end of the core: hand it to the second pass if this
-                        // lane owns it, drop it otherwise (it is never reported and the lane would
-                        // stop right after it)
-                        if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
-                            ZbLaneSave o2;
-                            o2.lp = lp; o2.mu = mu; o2.omega = omega; o2.last = last;
-                            o2.g = g; o2.ii = ii; o2.znext = znext; o2.n_pk = n_pk; o2.n_chips = n_chips;
-                            o2.s = s;
+                // the sequential receiver stops once it is idle past the end of its core
+                if (s.state == 0 && s.preamble_cnt == 0 && pos + origin >= rel_core_end) { done = true; break; }
+            }
+            n_chips += c;       // chips the sequential lane would have consumed so far
+            if (!done && !RESUME && pos + origin >= rel_core_end) {
+                // inside a frame at the end of the core: hand it to the second pass if this lane owns
+                // it, drop it otherwise (never reported, and the lane would stop right after it)
+                if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
+                    ZbLaneSave o2;
+                    o2.lp = lp; o2.mu = mu; o2.omega = omega; o2.last = last;
+                    o2.g = g; o2.ii = ii; o2.znext = znext; o2.n_pk = n_pk; o2.n_chips = n_chips;
+                    o2.s = s;
 #pragma unroll
-                            for (uint32_t k = 0; k < 16u; k++)
-                                o2.zhist[k] = ring[((znext - 16u + k) & (kRingRows - 1)) * kRingStride + l];
-                            saves[atomicAdd(n_saves, 1u)] = o2;
-                        }
-                        done = true;
-                        break;
-                    }
+                    for (uint32_t k = 0; k < 16u; k++)
+                        o2.zhist[k] = ring[((znext - 16u + k) & (kRingRows - 1)) * kRingStride + l];
+                    saves[atomicAdd(n_saves, 1u)] = o2;
                 }
+                done = true;
             }
             if (hi >= avail && ii + 8u > avail) done = true;      // ran out of samples
         }
@@ -547,7 +562,7 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int so
                        d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
                        d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(),
                        d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
-                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn, ablate);
+                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
     // second pass: the lanes that stopped inside a frame (grid covers the worst case; waves beyond
     // the saved count exit at once)
     hipLaunchKernelGGL(zb_lanes<true>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
@@ -555,7 +570,7 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int so
                        d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
                        d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(),
                        d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
-                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn, ablate);
+                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
     SNOUT_HIP(hipGetLastError());
     return 0;
 }
