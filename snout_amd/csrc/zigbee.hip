@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
 // ---------------------------------------------------------------------------------------------
 // a5-a7: lanes.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRingRows = 128;     // two 64-sample tiles
-constexpr int kRingStride = 65;
+constexpr int kRingLen = 128;      // two 64-sample tiles of history per lane
+constexpr int kRingStride = 137;   // per-lane row: 128 + 8 mirrored entries, odd -> bank = (lane + time) mod 32
+// ring[lane * kRingStride + (t & 127)] holds sample t of the lane; entries 128..135 mirror 0..7 so an
+// 8-sample window never wraps and is read with immediate offsets from one address.
 
 struct SinkState {
     int state;          // 0 search, 1 have_sync, 2 have_header
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
     float* __restrict__ soft_z, float* __restrict__ soft_chips,
     uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n)
 {
-    __shared__ float ring[kRingRows * kRingStride];
+    __shared__ float ring[64 * kRingStride];
     __shared__ __attribute__((aligned(16))) float taps[129 * 8];
     const uint32_t l = threadIdx.x;
     for (uint32_t i = l; i < 129u * 8u; i += 64u) taps[i] = mmse[i];
@@ -294,16 +296,16 @@ __global__ __launch_bounds__(64) void zb_lanes(
         const uint32_t r0 = tile * 64u;
         // ---- stage the prefetched tile: thread l holds sample r0+l of every row (lane)
         {
-            const uint32_t rr = ((r0 + l) & (kRingRows - 1)) * kRingStride;
+            const uint32_t tt = (r0 + l) & (kRingLen - 1);
 #pragma unroll
-            for (uint32_t row = 0; row < 64u; row++) ring[rr + row] = pre[row];
+            for (uint32_t row = 0; row < 64u; row++) ring[row * kRingStride + tt] = pre[row];
         }
         __builtin_amdgcn_wave_barrier();    // one wave per workgroup: LDS is program-ordered
         fetch_tile(r0 + 64u);               // in flight while this tile is processed
         if constexpr (RESUME) {
             if (tile == 0 && active) {      // the 16 filtered samples before znext
 #pragma unroll
-                for (uint32_t k = 0; k < 16u; k++) ring[((48u + k) & (kRingRows - 1)) * kRingStride + l] = sv.zhist[k];
+                for (uint32_t k = 0; k < 16u; k++) ring[l * kRingStride + 48u + k] = sv.zhist[k];
             }
         }
         const uint32_t staged = r0 + 64u;
@@ -316,32 +318,49 @@ __global__ __launch_bounds__(64) void zb_lanes(
             uint64_t cw = 0, d_lo = 0, d_hi = 0;
             uint32_t nc = 0;
             const uint32_t ii_start = ii;
-            while (ii + 8u <= hi) {
-                if (znext < ii + 8u) {
-                    // a5: DC removal, lazily, 8 samples at a time (sequential fp64 recurrence)
-                    if (znext + 8u > staged) break;             // next tile needed
+            float* row = &ring[l * kRingStride];
+            // a5: DC removal of the staged tile (sequential fp64 recurrence, 8 samples per step);
+            // a resumed lane's first tile is already filtered (its last 16 values were restored)
+            if (!(RESUME && tile == 0)) {
+                const uint32_t t0 = r0 & (kRingLen - 1);
+#pragma unroll 2
+                for (uint32_t q = 0; q < 64u; q += 8u) {
                     float xv[8];
 #pragma unroll
-                    for (uint32_t k = 0; k < 8u; k++) xv[k] = ring[((znext + k) & (kRingRows - 1)) * kRingStride + l];
+                    for (uint32_t k = 0; k < 8u; k++) xv[k] = row[t0 + q + k];
 #pragma unroll
                     for (uint32_t k = 0; k < 8u; k++) {
                         lp = alpha * (double)xv[k] + one_minus * lp;
-                        const float zz = xv[k] - (float)lp;
-                        ring[((znext + k) & (kRingRows - 1)) * kRingStride + l] = zz;
-                        if (tap && soft_z && znext + k + origin < soft_cap) soft_z[znext + k + origin] = zz;
+                        xv[k] = xv[k] - (float)lp;
+                        row[t0 + q + k] = xv[k];
                     }
-                    znext += 8u;
-                    continue;
+                    if (t0 + q == 0u) {                 // mirror of entries 0..7
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++) row[kRingLen + k] = xv[k];
+                    }
+                    if (tap && soft_z) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++)
+                            if (r0 + q + k + origin < soft_cap) soft_z[r0 + q + k + origin] = xv[k];
+                    }
                 }
-                // a6: Mueller & Mueller step with the 8-tap MMSE interpolator
+                znext = staged;
+            }
+            // a6: Mueller & Mueller steps with the 8-tap MMSE interpolator
+            while (ii + 8u <= hi) {
                 const int imu = (int)rintf(mu * 128.0f);
                 const float4 t0 = *reinterpret_cast<const float4*>(&taps[imu * 8]);
                 const float4 t1 = *reinterpret_cast<const float4*>(&taps[imu * 8 + 4]);
-                const float tp[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const float* w = &row[ii & (kRingLen - 1)];        // 8 consecutive samples, no wrap
                 float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    acc = __builtin_fmaf(tp[k], ring[((ii + 7u - k) & (kRingRows - 1)) * kRingStride + l], acc);
+                acc = __builtin_fmaf(t0.x, w[7], acc);
+                acc = __builtin_fmaf(t0.y, w[6], acc);
+                acc = __builtin_fmaf(t0.z, w[5], acc);
+                acc = __builtin_fmaf(t0.w, w[4], acc);
+                acc = __builtin_fmaf(t1.x, w[3], acc);
+                acc = __builtin_fmaf(t1.y, w[2], acc);
+                acc = __builtin_fmaf(t1.z, w[1], acc);
+                acc = __builtin_fmaf(t1.w, w[0], acc);
                 const float o = acc;
                 if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o;
                 const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
@@ -427,7 +446,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
                     o2.s = s;
 #pragma unroll
                     for (uint32_t k = 0; k < 16u; k++)
-                        o2.zhist[k] = ring[((znext - 16u + k) & (kRingRows - 1)) * kRingStride + l];
+                        o2.zhist[k] = row[((znext - 16u + k) & (kRingLen - 1))];
                     saves[atomicAdd(n_saves, 1u)] = o2;
                 }
                 done = true;
