@@ -30,6 +30,8 @@ const float*    oracle_zb_mmse_taps(void);
 float    oracle_fast_atan2f(float y, float x);
 void     oracle_zb_discrim(const float* iq, uint64_t n, float* d);
 uint16_t oracle_crc16_154(const uint8_t* d, int n);
+void     oracle_zb_iir_tables(double w[64], double* d64);
+double*  oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t warmup, uint64_t n_lanes);
 int      oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,
                                uint32_t threshold, uint32_t core, uint32_t warmup,
                                snout_pkt* out, uint64_t cap, uint64_t* n_out);

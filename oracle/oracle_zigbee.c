@@ -217,7 +217,8 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
 static void run_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t core_len,
                      uint64_t warmup, unsigned th, uint32_t channel, uint64_t first_index,
                      uint32_t lane_id, snout_pkt* out, uint64_t cap, uint64_t* n_out,
-                     float* soft_z, float* soft_chips, uint64_t soft_cap, uint64_t* n_chips)
+                     float* soft_z, float* soft_chips, uint64_t soft_cap, uint64_t* n_chips,
+                     double lp_init)
 {
     const uint64_t s0 = core_start > warmup ? core_start - warmup : 0;
     const uint64_t core_end = core_start + core_len;
@@ -227,6 +228,7 @@ static void run_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t c
     lane_t s;
     memset(&s, 0, sizeof(s));
     s.mu = 0.5f; s.omega = 2.0f; s.last = 0.0f;
+    s.lp = lp_init;       /* IIR state carried in from the samples before the lane (see below) */
     enter_search(&s);
     /* z is produced lazily: z_have = number of lane-relative samples filtered so far */
     float win[8];
@@ -296,6 +298,70 @@ static void run_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t c
     if (n_chips) *n_chips = chips;
 }
 
+/*
+ * IIR carry-in.  GNU Radio's single-pole IIR runs over the continuous stream, so when a frame
+ * arrives its DC estimate has long converged (time constant 1/alpha = 6250 samples).  A lane that
+ * started the recurrence from zero would see the uncorrected CFO offset for its first thousands of
+ * samples.  The linear recurrence is therefore carried across lanes exactly as a blocked evaluation
+ * of the same filter (all in double, fixed operation order, the GPU does the same):
+ *   S_j   = sum over the 64 samples of sub-block j of  w[63-k] * d[64 j + k],  w[m] = alpha (1-alpha)^m,
+ *           terms summed pairwise: v[i] += v[i+off] for off = 32,16,8,4,2,1   (zero-state response)
+ *   L_i   = fold over the sub-blocks of lane block i:  L = D64 * L + S_j
+ *   lp_in[i+1] = Dblk_i * lp_in[i] + L_i ,  lp_in[0] = 0
+ * where lane block i = [s0_i, s0_{i+1}), s0_i = max(0, i core - warmup), D64 = (1-alpha)^64 and
+ * Dblk_i = D64^(sub-blocks of the block), powers formed by repeated multiplication.
+ * Requires core and warmup to be multiples of 64.
+ */
+void oracle_zb_iir_tables(double w[64], double* d64)
+{
+    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+    double v = alpha;
+    for (int m = 0; m < 64; m++) { w[m] = v; v = v * one_minus; }
+    double p = 1.0;
+    for (int m = 0; m < 64; m++) p = p * one_minus;
+    *d64 = p;
+}
+
+static double pow_rep(double base, uint64_t e)
+{
+    double p = 1.0;
+    for (uint64_t k = 0; k < e; k++) p = p * base;
+    return p;
+}
+
+/* lp_in[l] for every lane l of one channel; returns malloc'ed array of n_lanes doubles */
+double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t warmup, uint64_t n_lanes)
+{
+    double w[64], d64;
+    oracle_zb_iir_tables(w, &d64);
+    const uint64_t nsb = (n + 63) / 64;
+    double* S = (double*)malloc((nsb ? nsb : 1) * sizeof(double));
+    for (uint64_t j = 0; j < nsb; j++) {
+        double v[64];
+        for (int k = 0; k < 64; k++) {
+            const uint64_t t = 64 * j + (uint64_t)k;
+            v[k] = w[63 - k] * (double)(t < n ? d[t] : 0.0f);
+        }
+        for (int off = 32; off >= 1; off >>= 1)
+            for (int i = 0; i < off; i++) v[i] = v[i] + v[i + off];
+        S[j] = v[0];
+    }
+    double* lp_in = (double*)malloc((n_lanes ? n_lanes : 1) * sizeof(double));
+    const double dcore = pow_rep(d64, core / 64u);
+    const double dfirst = pow_rep(d64, core > warmup ? (core - warmup) / 64u : 0u);
+    double lp = 0.0;
+    for (uint64_t l = 0; l < n_lanes; l++) {
+        lp_in[l] = lp;
+        const uint64_t b0 = l == 0 ? 0 : ((uint64_t)l * core - warmup) / 64u;      /* first sub-block */
+        const uint64_t b1 = ((uint64_t)(l + 1) * core - warmup) / 64u;             /* one past last   */
+        double L = 0.0;
+        for (uint64_t j = b0; j < b1; j++) L = d64 * L + (j < nsb ? S[j] : 0.0);
+        lp = (l == 0 ? dfirst : dcore) * lp + L;
+    }
+    free(S);
+    return lp_in;
+}
+
 int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,
                           uint32_t threshold, uint32_t core, uint32_t warmup,
                           snout_pkt* out, uint64_t cap, uint64_t* n_out)
@@ -305,10 +371,13 @@ int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uin
     float* d = (float*)malloc(n * sizeof(float));
     if (!d) return -3;
     oracle_zb_discrim(iq, n, d);
+    if (core % 64u || warmup % 64u || warmup >= core) { free(d); return -1; }
     const uint64_t n_lanes = (n + core - 1) / core;
+    double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
     for (uint64_t l = 0; l < n_lanes; l++)
         run_lane(d, n, l * core, core, warmup, threshold, channel, first_index, (uint32_t)l, out,
-                 cap, n_out, NULL, NULL, 0, NULL);
+                 cap, n_out, NULL, NULL, 0, NULL, lp_in[l]);
+    free(lp_in);
     free(d);
     return *n_out > cap ? -5 : 0;
 }
@@ -323,8 +392,11 @@ int oracle_zigbee_lane_soft(const float* iq, uint64_t n, uint32_t core, uint32_t
     oracle_zb_discrim(iq, n, d);
     snout_pkt tmp[64];
     uint64_t cnt = 0;
+    const uint64_t n_lanes = (n + core - 1) / core;
+    double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
     run_lane(d, n, (uint64_t)lane * core, core, warmup, threshold, 0, 0, lane, tmp, 64, &cnt, z, chips,
-             cap, n_chips);
+             cap, n_chips, lane < n_lanes ? lp_in[lane] : 0.0);
+    free(lp_in);
     free(d);
     return 0;
 }

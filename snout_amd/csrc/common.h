@@ -123,13 +123,16 @@ struct PfbCtx {
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
 struct ZbCtx {
-    uint32_t n_slots = 0, threshold = 10, core = 16384, warmup = 2048;
+    uint32_t n_slots = 0, threshold = 10, core = 4096, warmup = 1024;
     uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
     uint32_t ablate = 0;            // dev: skip stages (wrong results) to price them
     uint64_t d_stride = 0;
     bool overflow = false;
     DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft, d_saves;
+    DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
+    double d64 = 0, dcore = 0, dfirst = 0;
+    uint64_t nsb = 0;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
              uint32_t warmup);

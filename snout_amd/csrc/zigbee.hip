@@ -59,26 +59,74 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     return ang;
 }
 
+// One wave per 64-sample sub-block of one channel.  Besides d[t] the wave emits S_j, the
+// zero-state response of the single-pole IIR to its 64 samples (double, fixed pairwise order), from
+// which zb_iir_carry builds every lane's initial filter state (the "IIR carry-in", see the oracle).
 __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq, uint64_t n,
-                                                  uint64_t iq_stride, uint32_t n_slots,
+                                                  uint64_t iq_stride, uint32_t n_slots, uint64_t nsb,
                                                   const float* __restrict__ atan_tab,
-                                                  float* __restrict__ d, uint64_t d_stride)
+                                                  const double* __restrict__ iir_w,
+                                                  float* __restrict__ d, uint64_t d_stride,
+                                                  double* __restrict__ S)
 {
     __shared__ float tab[257];
+    __shared__ double wts[64];
     for (uint32_t i = threadIdx.x; i < 257; i += 256) tab[i] = atan_tab[i];
+    if (threadIdx.x < 64) wts[threadIdx.x] = iir_w[threadIdx.x];
     __syncthreads();
-    const uint64_t total = n * n_slots;
-    for (uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x; g < total;
-         g += (uint64_t)gridDim.x * 256u) {
-        const uint64_t slot = g / n, t = g - slot * n;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t total = nsb * n_slots;
+    for (uint64_t w = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); w < total;
+         w += (uint64_t)gridDim.x * 4u) {
+        const uint64_t slot = w / nsb, j = w - slot * nsb;
+        const uint64_t t = 64u * j + lane;
         const float2* x = iq + slot * iq_stride;
-        const float2 a = x[t];
-        const float2 p = t ? x[t - 1] : make_float2(0.0f, 0.0f);
-        const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
-        const float im = a.y * p.x - a.x * p.y;
-        float ang = fast_atan2f_tab(im, re, tab);
-        if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
-        d[slot * d_stride + t] = ang;
+        float ang = 0.0f;
+        if (t < n) {
+            const float2 a = x[t];
+            const float2 p = t ? x[t - 1] : make_float2(0.0f, 0.0f);
+            const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
+            const float im = a.y * p.x - a.x * p.y;
+            ang = fast_atan2f_tab(im, re, tab);
+            if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
+            d[slot * d_stride + t] = ang;
+        }
+        double v = wts[63u - lane] * (double)ang;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off);
+        if (lane == 0) S[slot * nsb + j] = v;
+    }
+}
+
+// Lane block i = [s0_i, s0_{i+1}): fold its sub-block sums, L = D64 L + S_j (one thread per lane).
+__global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S, uint64_t nsb,
+                                                   uint32_t lanes_per_slot, uint32_t total_lanes,
+                                                   uint32_t core, uint32_t warmup, double d64,
+                                                   double* __restrict__ Lblk)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_lanes) return;
+    const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
+    const uint64_t b0 = li == 0 ? 0ull : ((uint64_t)li * core - warmup) / 64u;
+    const uint64_t b1 = ((uint64_t)(li + 1) * core - warmup) / 64u;
+    const double* s = S + (uint64_t)slot * nsb;
+    double L = 0.0;
+    for (uint64_t j = b0; j < b1; j++) L = d64 * L + (j < nsb ? s[j] : 0.0);
+    Lblk[g] = L;
+}
+
+// lp_in[i+1] = Dblk_i lp_in[i] + L_i along the lanes of a channel (one thread per channel).
+__global__ __launch_bounds__(64) void zb_iir_scan(const double* __restrict__ Lblk, uint32_t lanes_per_slot,
+                                                  uint32_t n_slots, double dfirst, double dcore,
+                                                  double* __restrict__ lp_in)
+{
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    if (slot >= n_slots) return;
+    double lp = 0.0;
+    for (uint32_t l = 0; l < lanes_per_slot; l++) {
+        const uint32_t g = slot * lanes_per_slot + l;
+        lp_in[g] = lp;
+        lp = (l == 0 ? dfirst : dcore) * lp + Lblk[g];
     }
 }
 
@@ -219,7 +267,8 @@ __global__ __launch_bounds__(64) void zb_lanes(
     uint32_t total_lanes, uint32_t core, uint32_t warmup, uint32_t th,
     const uint16_t* __restrict__ slot_channel, uint64_t first_index,
     const float* __restrict__ mmse, snout_pkt* __restrict__ stage, uint32_t K,
-    uint32_t* __restrict__ lane_cnt, ZbLaneSave* __restrict__ saves, uint32_t* __restrict__ n_saves,
+    uint32_t* __restrict__ lane_cnt, const double* __restrict__ lp_in,
+    ZbLaneSave* __restrict__ saves, uint32_t* __restrict__ n_saves,
     float* __restrict__ soft_z, float* __restrict__ soft_chips,
     uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n)
 {
@@ -256,7 +305,7 @@ __global__ __launch_bounds__(64) void zb_lanes(
     const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
     const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
     const float omega_lim = omega_mid * 0.0002f;
-    double lp = 0.0;
+    double lp = (!RESUME && active) ? lp_in[g] : 0.0;    // IIR state carried in from before the lane
     float mu = 0.5f, omega = 2.0f, last = 0.0f;
     SinkState s;
     enter_search(s);
@@ -537,8 +586,25 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
     threshold = threshold_;
     core = core_;
     warmup = warmup_;
+    if (core % 64u || warmup % 64u || warmup >= core) {
+        set_last_error("zb_core (%u) and zb_warmup (%u) must be multiples of 64, warmup < core", core, warmup);
+        return SNOUT_EINVAL;
+    }
     std::vector<float> atan_tab(257);
     for (int i = 0; i < 257; i++) atan_tab[i] = (float)atan((double)i / 255.0);
+    {   // IIR carry-in tables: w[m] = alpha (1-alpha)^m, D64 = (1-alpha)^64, block decay factors
+        const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+        double w[64], v = alpha, p = 1.0;
+        for (int m = 0; m < 64; m++) { w[m] = v; v = v * one_minus; }
+        for (int m = 0; m < 64; m++) p = p * one_minus;
+        d64 = p;
+        dcore = 1.0;
+        for (uint32_t k = 0; k < core / 64u; k++) dcore = dcore * d64;
+        dfirst = 1.0;
+        for (uint32_t k = 0; k < (core - warmup) / 64u; k++) dfirst = dfirst * d64;
+        if (int rc = d_iirw.ensure(64 * 8)) return rc;
+        SNOUT_HIP(hipMemcpy(d_iirw.p, w, 64 * 8, hipMemcpyHostToDevice));
+    }
     if (int rc = d_atan.ensure(257 * 4)) return rc;
     if (int rc = d_mmse.ensure(129 * 8 * 4)) return rc;
     if (int rc = d_slot_channel.ensure(n_slots * 2)) return rc;
@@ -552,6 +618,7 @@ void ZbCtx::destroy()
 {
     d_atan.release(); d_mmse.release(); d_slot_channel.release();
     d_d.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release(); d_saves.release();
+    d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
 }
 
 int ZbCtx::reserve(uint64_t n)
@@ -566,6 +633,10 @@ int ZbCtx::reserve(uint64_t n)
     max_out = total_lanes * pkts_per_lane;
     if (int rc = d_soft.ensure(((uint64_t)kSoftCap * 2u + 16u) * 4u)) return rc;
     if (int rc = d_saves.ensure((uint64_t)total_lanes * sizeof(ZbLaneSave))) return rc;
+    nsb = (n + 63u) / 64u;
+    if (int rc = d_S.ensure(nsb * n_slots * 8u)) return rc;
+    if (int rc = d_Lblk.ensure((uint64_t)total_lanes * 8u)) return rc;
+    if (int rc = d_lp_in.ensure((uint64_t)total_lanes * 8u)) return rc;
     return 0;
 }
 
@@ -579,7 +650,7 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int so
     hipLaunchKernelGGL(zb_lanes<false>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
                        d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
-                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(),
+                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), d_lp_in.as<double>(),
                        d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
                        (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
     // second pass: the lanes that stopped inside a frame (grid covers the worst case; waves beyond
@@ -587,7 +658,7 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int so
     hipLaunchKernelGGL(zb_lanes<true>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
                        d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
-                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(),
+                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), d_lp_in.as<double>(),
                        d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
                        (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
     SNOUT_HIP(hipGetLastError());
@@ -643,9 +714,14 @@ int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t f
     uint32_t* sums = tot + 16;
     uint32_t* over = tot + 16 + kMaxTiles;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
-    const uint32_t gd = std::min<uint32_t>(cdiv(n * n_slots, 256), 256u * 16u);
+    const uint32_t gd = std::min<uint32_t>(cdiv(nsb * n_slots, 4), 256u * 16u);
     hipLaunchKernelGGL(zb_discrim, dim3(gd), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
-                       n_slots, d_atan.as<float>(), d_d.as<float>(), d_stride);
+                       n_slots, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(), d_stride,
+                       d_S.as<double>());
+    hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
+                       lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
+    hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(n_slots, 64)), dim3(64), 0, st, d_Lblk.as<double>(),
+                       lanes_per_slot, n_slots, dfirst, dcore, d_lp_in.as<double>());
     if (int rc = launch_lanes(n, first_index, st, -1)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
