@@ -115,18 +115,28 @@ __global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S,
     Lblk[g] = L;
 }
 
-// lp_in[i+1] = Dblk_i lp_in[i] + L_i along the lanes of a channel (one thread per channel).
+// lp_in[i+1] = Dblk_i lp_in[i] + L_i along the lanes of a channel: one wave per channel walks the
+// lanes 64 at a time (coalesced load of L, then the sequential recurrence with v_readlane).
 __global__ __launch_bounds__(64) void zb_iir_scan(const double* __restrict__ Lblk, uint32_t lanes_per_slot,
                                                   uint32_t n_slots, double dfirst, double dcore,
                                                   double* __restrict__ lp_in)
 {
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
     if (slot >= n_slots) return;
     double lp = 0.0;
-    for (uint32_t l = 0; l < lanes_per_slot; l++) {
-        const uint32_t g = slot * lanes_per_slot + l;
-        lp_in[g] = lp;
-        lp = (l == 0 ? dfirst : dcore) * lp + Lblk[g];
+    double nxt = lane < lanes_per_slot ? Lblk[slot * lanes_per_slot + lane] : 0.0;
+    for (uint32_t l0 = 0; l0 < lanes_per_slot; l0 += 64u) {
+        const uint32_t g = slot * lanes_per_slot + l0 + lane;
+        const double v = nxt;
+        nxt = (l0 + 64u + lane < lanes_per_slot) ? Lblk[g + 64u] : 0.0;     // in flight during the chain
+        double mine = 0.0;
+#pragma unroll 8
+        for (uint32_t i = 0; i < 64u; i++) {
+            if (lane == i) mine = lp;                          // state before lane l0+i
+            const double Li = __shfl(v, (int)i);
+            lp = ((l0 + i) == 0u ? dfirst : dcore) * lp + Li;
+        }
+        if (l0 + lane < lanes_per_slot) lp_in[g] = mine;
     }
 }
 
@@ -720,7 +730,7 @@ int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t f
                        d_S.as<double>());
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
-    hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(n_slots, 64)), dim3(64), 0, st, d_Lblk.as<double>(),
+    hipLaunchKernelGGL(zb_iir_scan, dim3(n_slots), dim3(64), 0, st, d_Lblk.as<double>(),
                        lanes_per_slot, n_slots, dfirst, dcore, d_lp_in.as<double>());
     if (int rc = launch_lanes(n, first_index, st, -1)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
