@@ -134,6 +134,8 @@ def main():
                 last = finish_one()
             return last
         for i in range(k):
+            if gather is not None:
+                gather.sync_uploads()       # result slots about to be reused have been read
             rx.submit(x, first_sample_index=rank * n)
             if i:
                 last = finish_one()

@@ -87,8 +87,8 @@ class AsyncRecordGather:
     gathered block into pinned host memory; ``finish()`` waits for the oldest started gather and
     returns the records (rank 0) or None.  Two gathers may be in flight, so the exchange of step i
     overlaps the kernels of step i+1.  Every rank sends ``cap`` record slots preceded by a header
-    slot holding its count; ``cap`` is agreed once (max over ranks + 25 %) and re-agreed only if a
-    rank ever exceeds it.  ``width`` < 160 gathers only the first ``width`` bytes of each record
+    slot holding its count; ``cap`` is agreed once, at the first start(): twice the largest count of
+    any rank.  ``width`` < 160 gathers only the first ``width`` bytes of each record
     (BTLE records use at most 24 + 42 bytes; the rest is zero by construction).
     """
 
@@ -116,7 +116,7 @@ class AsyncRecordGather:
         t = self.torch.tensor([n], dtype=self.torch.int64, device=self.device)
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        self.cap = int(t.item()) + int(t.item()) // 4 + 256
+        self.cap = 2 * int(t.item()) + 1024
         torch = self.torch
         self.slots = []
         for _ in range(2):
@@ -126,7 +126,8 @@ class AsyncRecordGather:
             host = torch.zeros(recv.shape, dtype=torch.uint8,
                                pin_memory=self.on_gpu) if self.rank == 0 else None
             ev = torch.cuda.Event() if self.on_gpu else None
-            self.slots.append(dict(send=send, recv=recv, host=host, ev=ev))
+            up = torch.cuda.Event() if self.on_gpu else None
+            self.slots.append(dict(send=send, recv=recv, host=host, ev=ev, up=up))
         self.next = 0
 
     def start(self, rec: np.ndarray) -> None:
@@ -134,10 +135,12 @@ class AsyncRecordGather:
         n = int(rec.size)
         while len(self.inflight) >= 2:
             raise RuntimeError("two gathers in flight: finish() one first")
-        if n > self.cap or not self.slots:
-            # (re)negotiate the slot count; collective and synchronous, so drain first
-            assert not self.inflight, "capacity change with gathers in flight"
-            self._agree_cap(n)
+        if not self.slots:
+            self._agree_cap(n)      # collective: every rank makes its first start() together
+        if n > self.cap:
+            # re-agreeing is a collective every rank would have to enter at the same step
+            raise RuntimeError(f"rank {self.rank}: {n} records exceed the agreed gather capacity "
+                               f"{self.cap} (2x the largest first-step count)")
         slot = self.slots[self.next]
         self.next ^= 1
         hdr = np.zeros(self.width, dtype=np.uint8)
@@ -152,6 +155,8 @@ class AsyncRecordGather:
             if n:
                 view = send[self.width:(n + 1) * self.width].view(n, self.width)
                 view.copy_(torch.from_numpy(src), non_blocking=True)
+            if self.on_gpu:
+                slot["up"].record(self.stream)       # the caller's record buffer may be reused after this
             if self.world > 1:
                 self.dist.all_gather_into_tensor(slot["recv"], send, group=self.group)
             else:
@@ -161,6 +166,13 @@ class AsyncRecordGather:
             if self.on_gpu:
                 slot["ev"].record(self.stream)
         self.inflight.append(slot)
+
+    def sync_uploads(self) -> None:
+        """Block until the record buffers handed to start() have been read (they may be views of
+        a receiver's pinned result slot that the next submit will overwrite)."""
+        if self.on_gpu:
+            for slot in self.inflight:
+                slot["up"].synchronize()
 
     def finish(self) -> Optional[np.ndarray]:
         if not self.inflight:
