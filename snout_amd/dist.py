@@ -35,16 +35,22 @@ def shard_segments(n_total: int, seg_len: int, overlap: int, rank: int, world: i
     return out
 
 
-def dedup_records(rec: np.ndarray) -> np.ndarray:
-    """Sort by (proto, channel, sample_index) and drop duplicates found by overlapping segments."""
+def dedup_records(rec: np.ndarray, tol: int = 0) -> np.ndarray:
+    """Sort by (proto, channel, sample_index) and drop duplicates found by overlapping segments.
+    ``tol`` > 0: records of the same channel with equal bytes whose sample_index differs by at most
+    ``tol`` are the same frame (802.15.4: each run may first recognise a different one of the 8
+    preamble symbols, 64 samples apart, and its timing loop locks at its own phase)."""
     if rec.size == 0:
         return rec
     order = np.lexsort((rec["sample_index"], rec["channel"], rec["proto"]))
     rec = rec[order]
-    key = np.stack([rec["proto"].astype(np.uint64), rec["channel"].astype(np.uint64),
-                    rec["sample_index"]], axis=1)
+    same_ch = (rec["proto"][1:] == rec["proto"][:-1]) & (rec["channel"][1:] == rec["channel"][:-1])
+    dsi = rec["sample_index"][1:].astype(np.int64) - rec["sample_index"][:-1].astype(np.int64)
+    dup = same_ch & (dsi <= tol)
+    if tol > 0:
+        dup &= (rec["len"][1:] == rec["len"][:-1]) & np.all(rec["bytes"][1:] == rec["bytes"][:-1], axis=1)
     keep = np.ones(rec.size, dtype=bool)
-    keep[1:] = np.any(key[1:] != key[:-1], axis=1)
+    keep[1:] = ~dup
     return rec[keep]
 
 

@@ -94,3 +94,14 @@ def test_gather_records_gloo_world2():
         want = [10000 * step + i for i in range(2 + step)] + [10000 * step + 100 + i for i in range(3 + step)]
         assert seq[step] == want
     assert len(seq[3]) == 1400 and seq[3][0] == 30000 and seq[3][700] == 30100
+
+
+def test_dedup_with_tolerance():
+    r = _recs([(1, 11, 1000), (1, 11, 1030), (1, 11, 5000), (1, 12, 1001)])
+    r["bytes"][:, 0] = [7, 7, 7, 7]
+    r["len"] = 5
+    assert len(sdist.dedup_records(r, tol=0)) == 4
+    d = sdist.dedup_records(r, tol=64)
+    assert [int(x["sample_index"]) for x in d] == [1000, 5000, 1001]
+    r["bytes"][1, 1] = 9                                       # different payload: not a duplicate
+    assert len(sdist.dedup_records(r, tol=64)) == 4
