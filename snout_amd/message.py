@@ -24,6 +24,12 @@ class BtleMessage:
     protocol: str = "btle"
     meta: dict = field(default_factory=dict)
 
+    @property
+    def payload(self) -> dict:
+        """Dissected AdvData (BtlePDUPayload.fromstring(...).dict() in the reference, message.py:232)."""
+        from .advertising import dissect_hex
+        return dissect_hex(self.payload_hex)
+
     @classmethod
     def fromraw(cls, raw_message: Optional[bytes]):
         if not raw_message:

@@ -168,16 +168,22 @@ class ZigbeeScan:
         x = self.source.read(channel)
         with SnoutRx(proto=_ffi.PROTO_ZIGBEE, channel=channel, device=self.device) as rx:
             start = 0
-            seen_until = -1
+            recent = []                     # (sample_index, bytes) of frames near the segment seam
             while start < len(x):
                 stop = min(start + SEGMENT + ZIGBEE_OVERLAP, len(x))
+                fresh = []
                 for p in rx.process(x[start:stop], first_sample_index=start):
                     si = int(p["sample_index"])
-                    if si <= seen_until:
+                    body = bytes(p["bytes"][:p["len"]])
+                    # found again in the overlap: same bytes, first preamble symbol recognised within
+                    # 8 symbols (64 samples each) of the earlier run
+                    if any(abs(si - s0) <= 8 * 64 + 8 and body == b0 for s0, b0 in recent):
                         continue
-                    seen_until = si
+                    if si >= start + SEGMENT - 8 * 64:
+                        fresh.append((si, body))
                     self._elapsed = si / ZIGBEE_FS
                     yield p
+                recent = fresh
                 start += SEGMENT
 
     def run(self):
