@@ -112,8 +112,8 @@ def main():
     x, expect, pdus = make_workload(n, seed=2 + rank, device=device)
     rx = SnoutRx(proto=0, channel=37, device=local_rank)
 
-    # Pipelined steps: segment i+1 is submitted before the records of segment i are collected, so
-    # the record D2H (copy stream) overlaps the next segment's kernels.  Every step's records are
+    # Pipelined steps: up to three segments are in flight, so the next front-end kernel is already
+    # queued when the previous one ends and the record D2H (copy stream) overlaps compute.  Every step's records are
     # in host memory (and gathered to rank 0) before the timed region ends.
     gather = sdist.AsyncRecordGather(device, width=80) if world > 1 else None
 
@@ -137,11 +137,15 @@ def main():
             if gather is not None:
                 gather.sync_uploads()       # result slots about to be reused have been read
             rx.submit(x, first_sample_index=rank * n)
-            if i:
+            if i >= 2:                      # two segments stay queued behind the one being collected
                 last = finish_one()
-        return finish_one()
+        for _ in range(min(k, 2)):
+            last = finish_one()
+        return last
 
-    run_steps(4)            # prime the two-slot pipeline (first-use allocations of both slots)
+    # prime the pipeline: first-use allocations of the three result slots and the HIP runtime's own
+    # lazily grown pools (two ~7 ms stalls were measured around the 11th and 16th submit of a process)
+    run_steps(24)
     if args.warmup:
         run_steps(args.warmup)
 

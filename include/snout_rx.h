@@ -124,9 +124,9 @@ int  snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
                           uint64_t first_sample_index, void* hip_stream,
                           snout_pkt* out, uint64_t cap, uint64_t* n_out);
 
-/* Pipelined form: up to two segments may be in flight.  submit enqueues every kernel of a segment
+/* Pipelined form: up to three segments may be in flight.  submit enqueues every kernel of a segment
  * on hip_stream and returns without waiting; collect waits for the oldest submitted segment and
- * hands out its records (collect_view: a pointer into the handle's pinned buffer, valid until two
+ * hands out its records (collect_view: a pointer into the handle's pinned buffer, valid until three
  * more submits).  The record D2H of segment i runs on an internal copy stream and overlaps the
  * kernels of segment i+1.  iq_dev must stay valid and unchanged until its collect returns. */
 int  snout_rx_submit_dev  (snout_rx* h, const float* iq_dev, uint64_t n_samples,

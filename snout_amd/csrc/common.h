@@ -64,13 +64,15 @@ struct ResultSlot {
     uint32_t* h_totals = nullptr;        // pinned, 16 u32
     snout_pkt* h_recs = nullptr;         // pinned staging for records
     uint64_t h_cap = 0;
-    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_compute = nullptr, ev_copy = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_front = nullptr,
+               ev_compute = nullptr, ev_copy = nullptr;
     // bookkeeping of the submitted segment
     const float* iq = nullptr;
     uint64_t n_in = 0, first_index = 0, spec_copied = 0, n_pkts = 0;
     hipStream_t stream = nullptr;
     bool timed = false;
     int hist_idx = 0;                    // event pair of the handle's pool that timed this segment
+    int work_set = 0;                    // which BTLE work set (planes, lists, candidates) it runs on
     int init();
     void destroy();
     int ensure_host(uint64_t recs);

@@ -57,6 +57,7 @@ int ResultSlot::init()
     SNOUT_HIP(hipEventCreate(&ev_t0));
     SNOUT_HIP(hipEventCreate(&ev_k0));
     SNOUT_HIP(hipEventCreate(&ev_k1));
+    SNOUT_HIP(hipEventCreate(&ev_front));
     SNOUT_HIP(hipEventCreate(&ev_compute));
     SNOUT_HIP(hipEventCreate(&ev_copy));
     return 0;
@@ -71,7 +72,7 @@ void ResultSlot::destroy()
     h_totals = nullptr; h_recs = nullptr; h_cap = 0;
     if (ev_t0) {
         (void)hipEventDestroy(ev_t0); (void)hipEventDestroy(ev_k0); (void)hipEventDestroy(ev_k1);
-        (void)hipEventDestroy(ev_compute); (void)hipEventDestroy(ev_copy);
+        (void)hipEventDestroy(ev_front); (void)hipEventDestroy(ev_compute); (void)hipEventDestroy(ev_copy);
         ev_t0 = nullptr;
     }
 }
@@ -94,11 +95,15 @@ struct snout_rx {
     snout_rx_cfg cfg;
     int device = 0;
     bool wide = false;
-    BtleCtx btle;
+    BtleCtx btle, btle2;      // two work sets: the tail of segment i overlaps the front end of i+1
+    hipStream_t tail_stream = nullptr;
     ZbCtx zb;
     PfbCtx pfb;
     DevBuf d_iq;              // staging for snout_rx_process (host input)
-    ResultSlot slots[2];
+    static constexpr int kSlots = 3;    // segments in flight: front end i+1 is queued before copy i-1 lands
+    ResultSlot slots[kSlots];
+    hipEvent_t ws_free[2] = {nullptr, nullptr};   // last tail that used BTLE work set k has finished
+    uint64_t n_submitted = 0;
     hipStream_t copy_stream = nullptr;
     int head = 0, pending = 0;          // ring of submitted, not yet collected segments
     uint64_t spec = 0;                  // records copied speculatively with the totals
@@ -112,32 +117,45 @@ struct snout_rx {
     uint64_t last_n = 0, last_nch = 0, last_pkts = 0;
 };
 
-// Enqueue every kernel of one segment on `st`, results into slot s.  No host synchronisation.
+static BtleCtx& btle_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->btle2 : h->btle; }
+
+// Enqueue every kernel of one segment, results into slot s.  No host synchronisation.
+// BTLE: the front end (demod+correlate, or channelizer+correlate) runs on the caller's stream `st`;
+// the O(candidates) tail runs on an internal stream behind an event, on the slot's own work set, so
+// the next segment's front end does not wait for it.
 static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
 {
     const float* ch_iq = s.iq;
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
     SNOUT_HIP(hipEventRecord(s.ev_t0, st));
+    if (h->cfg.proto == SNOUT_PROTO_BTLE)     // the tail that last used this work set must be done
+        SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));
     const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.reserved[0] & 1u);
     if (h->wide) {
         n_ch = h->pfb.n_out_for(s.n_in);
-        if (fused) { if (int rc = h->btle.reserve(n_ch)) return rc; }
+        BtleCtx& bw = btle_of(h, s);
+        if (fused) { if (int rc = bw.reserve(n_ch)) return rc; }
         SNOUT_HIP(hipEventRecord(s.ev_k0, st));
-        if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? h->btle.d_planes.as<uint16_t>() : nullptr,
-                                h->btle.plane_stride)) return rc;
+        if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
+                                bw.plane_stride)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         ch_iq = h->pfb.d_y.as<float>();
         ch_stride = h->pfb.y_stride;
     }
     if (h->cfg.proto == SNOUT_PROTO_BTLE) {
-        BtleCtx& b = h->btle;
+        BtleCtx& b = btle_of(h, s);
         if (int rc = b.reserve(n_ch)) return rc;
         if (fused) {
             if (int rc = b.launch_corr_planes(n_ch, st)) return rc;       // bits are already in the planes
         } else {
             if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s)) return rc;
         }
-        if (int rc = b.enqueue_tail(n_ch, s.first_index, st, s)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_front, st));
+        SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, s.ev_front, 0));
+        if (int rc = b.enqueue_tail(n_ch, s.first_index, h->tail_stream, s)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_compute, h->tail_stream));
+        SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], h->tail_stream));
+        return 0;
     } else {
         ZbCtx& z = h->zb;
         if (int rc = z.reserve(n_ch)) return rc;
@@ -170,9 +188,12 @@ static int finish_slot(snout_rx* h, ResultSlot& s)
 {
     for (int attempt = 0; attempt < 12; attempt++) {
         SNOUT_HIP(hipEventSynchronize(s.ev_copy));
-        const bool over = h->cfg.proto == SNOUT_PROTO_BTLE ? h->btle.check_overflow(s)
+        const bool over = h->cfg.proto == SNOUT_PROTO_BTLE ? btle_of(h, s).check_overflow(s)
                                                            : h->zb.check_overflow(s);
         if (!over) { s.n_pkts = s.h_totals[1]; return SNOUT_OK; }
+        // other segments in flight share this slot's work set every second submit: let them finish
+        // (their results are already on their way to their own slots) before reusing it
+        SNOUT_HIP(hipDeviceSynchronize());
         std::swap(s.ev_k0, h->hist_k0[s.hist_idx]);     // time the rerun with the same pool pair
         std::swap(s.ev_k1, h->hist_k1[s.hist_idx]);
         int rc = enqueue_segment(h, s, s.stream);
@@ -257,6 +278,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (c.channel > 39) { set_last_error("BTLE channel %u", c.channel); goto fail; }
         uint16_t ch = (uint16_t)c.channel;
         rc = h->btle.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
+        if (!rc) rc = h->btle2.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
         if (rc) goto fail;
     } else if (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 1) {
         if (c.channel < 11 || c.channel > 26) { set_last_error("Zigbee channel %u", c.channel); goto fail; }
@@ -277,6 +299,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (rc) goto fail;
         rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits)
                                          : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
+        if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle2.init(M, chs, c.access_addr, c.crc_init, c.max_hits);
         if (rc) goto fail;
     } else {
         set_last_error("configuration proto=%u n_channels=%u not supported (BTLE: 1 or 40, "
@@ -284,11 +307,19 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         goto fail;
     }
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
+    for (int k = 0; k < 2; k++) {
+        if (hipEventCreate(&h->ws_free[k]) != hipSuccess) { rc = SNOUT_EHIP; goto fail; }
+    }
     for (int i = 0; i < snout_rx::kHist; i++) {
         if (hipEventCreate(&h->hist_k0[i]) != hipSuccess || hipEventCreate(&h->hist_k1[i]) != hipSuccess) {
             rc = SNOUT_EHIP;
             goto fail;
         }
+    }
+    if (hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_last_error("hipStreamCreate failed");
+        rc = SNOUT_EHIP;
+        goto fail;
     }
     {   // highest priority: the short record copy must not queue behind the next segment's blocks
         int least = 0, greatest = 0;
@@ -312,10 +343,13 @@ void snout_rx_destroy(snout_rx* h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->btle.destroy();
+    h->btle2.destroy();
+    if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
     h->zb.destroy();
     h->pfb.destroy();
     h->d_iq.release();
     for (auto& s : h->slots) s.destroy();
+    for (int k = 0; k < 2; k++) if (h->ws_free[k]) (void)hipEventDestroy(h->ws_free[k]);
     for (int i = 0; i < snout_rx::kHist; i++) {
         if (h->hist_k0[i]) (void)hipEventDestroy(h->hist_k0[i]);
         if (h->hist_k1[i]) (void)hipEventDestroy(h->hist_k1[i]);
@@ -345,9 +379,13 @@ int snout_rx_submit_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
                         uint64_t first_sample_index, void* hip_stream)
 {
     if (int rc = check_segment(h, iq_dev, n_samples)) return rc;
-    if (h->pending >= 2) { set_last_error("two segments in flight: collect one first"); return SNOUT_EINVAL; }
+    if (h->pending >= snout_rx::kSlots) {
+        set_last_error("%d segments in flight: collect one first", snout_rx::kSlots);
+        return SNOUT_EINVAL;
+    }
     SNOUT_HIP(hipSetDevice(h->device));
-    ResultSlot& s = h->slots[(h->head + h->pending) & 1];
+    ResultSlot& s = h->slots[(h->head + h->pending) % snout_rx::kSlots];
+    s.work_set = (int)(h->n_submitted++ & 1u);
     s.iq = iq_dev;
     s.n_in = n_samples;
     s.first_index = first_sample_index;
@@ -387,7 +425,7 @@ int snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out)
     if (h->pending == 0) { set_last_error("nothing submitted"); return SNOUT_EINVAL; }
     SNOUT_HIP(hipSetDevice(h->device));
     ResultSlot& s = h->slots[h->head];
-    h->head ^= 1;
+    h->head = (h->head + 1) % snout_rx::kSlots;
     h->pending--;
     if (int rc = finish_slot(h, s)) return rc;
     const uint64_t np = s.n_pkts;
@@ -439,7 +477,7 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
     h->spec = spec_save;
     if (rc) return rc;
     ResultSlot& s = h->slots[h->head];
-    h->head ^= 1;
+    h->head = (h->head + 1) % snout_rx::kSlots;
     h->pending--;
     if ((rc = finish_slot(h, s))) return rc;
     uint64_t np = s.n_pkts;
@@ -545,7 +583,7 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
         return nf > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
     }
     if (stage == SNOUT_STAGE_BTLE_BITS && h->cfg.proto == SNOUT_PROTO_BTLE) {
-        BtleCtx& b = h->btle;
+        BtleCtx& b = btle_of(h, *h->last);
         if (channel_slot >= b.n_slots || h->last_nch < 5) return SNOUT_EINVAL;
         const uint64_t nb = h->last_nch - 4;
         const uint64_t words = (uint64_t)b.n_chunks * kChunkIters * 4u;

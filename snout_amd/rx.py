@@ -115,7 +115,7 @@ class SnoutRx:
             self._h, C.c_void_p(iq.data_ptr()), n, first_sample_index, C.c_void_p(st), *r),
             cap=max(4096, n // 2048), copy=copy)
 
-    # ---- pipelined form: up to two segments in flight ---------------------------------------
+    # ---- pipelined form: up to three segments in flight ---------------------------------------
     def submit(self, iq, first_sample_index: int = 0, stream: Optional[int] = None) -> None:
         """Enqueue one device-resident segment (torch CUDA tensor) without waiting. The tensor must
         stay alive and unchanged until the matching :meth:`collect`."""
@@ -129,7 +129,7 @@ class SnoutRx:
 
     def collect(self, copy: bool = True) -> np.ndarray:
         """Records of the oldest submitted segment. ``copy=False``: a view of the handle's pinned
-        buffer, valid until two more submits."""
+        buffer, valid until three more submits."""
         ptr = C.c_void_p()
         n = C.c_uint64(0)
         _ffi.check(self._lib.snout_rx_collect_view(self._h, C.byref(ptr), C.byref(n)))

@@ -134,8 +134,9 @@ def test_pipelined_submit_collect_matches_sync(oracle):
             rx.submit(segs[i][1], first_sample_index=i << 19)
             got.append(rx.collect())
         with pytest.raises(SnoutError):
-            rx.submit(segs[0][1]); rx.submit(segs[0][1]); rx.submit(segs[0][1])
-        rest = [rx.collect(), rx.collect()]
+            for _ in range(4):
+                rx.submit(segs[0][1])
+        rest = [rx.collect(), rx.collect(), rx.collect()]
         got.append(rest[0]) if len(got) < len(segs) else None
         with pytest.raises(SnoutError):
             rx.collect()
