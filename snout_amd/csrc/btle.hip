@@ -116,7 +116,12 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
     for (int u = 0; u < DEPTH; u++) {
         const uint32_t voff = (uint32_t)u * 2048u + lane * 32u;      // rows past n_it read as 0 or
 #pragma unroll                                                       // belong to the next chunk: unused
-        for (int k = 0; k < 4; k++) q[u][k] = ld(voff + 16u * k);
+        for (int k = 0; k < 4; k++) q[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the warm-up row only feeds the 31-symbol history: its lower half is never looked at
+        if (!(u == 0 && it0 != itw && lane < 32u)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[u][k] = ld(voff + 16u * k);
+        }
     }
     for (uint32_t r0 = 0; r0 < n_it; r0 += DEPTH) {
 #pragma unroll
@@ -160,10 +165,12 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
             for (int j = 0; j < 4; j++) prev[j] = cur[j];
         }
     }
-    // one coalesced 2 KiB store of the chunk's bit planes: lane l holds iteration it0+l
-    uint64_t* dst = planes + ((size_t)it0 + lane) * 4u;
-    reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(keep[0], keep[1]);
-    reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(keep[2], keep[3]);
+    // one coalesced store of the chunk's bit planes: lane l holds iteration it0+l
+    if (lane < (uint32_t)kChunkIters) {
+        uint64_t* dst = planes + ((size_t)it0 + lane) * 4u;
+        reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(keep[0], keep[1]);
+        reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(keep[2], keep[3]);
+    }
     if (lane == 0) chunk_cnt[item] = cnt;
 }
 
