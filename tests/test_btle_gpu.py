@@ -182,3 +182,29 @@ def test_async_record_gather_over_rccl_world1():
             assert np.array_equal(o["bytes"], want["bytes"][:, :56])
     finally:
         dist.destroy_process_group()
+
+
+def test_btle_rx_child_process_drop_in():
+    """The reference drives `btle_rx` as a child and parses its stdout (snout/util/btle.py:53-76,
+    snout/core/pcontroller.py).  `snout_amd.cli btle-rx` takes the same argv and prints the same
+    lines: run it as a real subprocess on the cfg #1 recording, like tests/test_util_pcontroller.py
+    runs its stand-in scripts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from snout_amd.message import BtleMessage
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    out = subprocess.run([sys.executable, "-m", "snout_amd.cli", "btle-rx", "-c", "37", "-g", "6",
+                          "-a", "8e89bed6", "-k", "555555", "--iq",
+                          os.path.join(gold, "btle_ch37_4msps.cf32")],
+                         cwd=root, capture_output=True, timeout=300, check=True)
+    lines = out.stdout.splitlines(keepends=True)
+    truth = json.load(open(os.path.join(gold, "btle_ch37_truth.json")))
+    msgs = [m for m in (BtleMessage.fromraw(ln) for ln in lines) if m]
+    assert len(msgs) == 8
+    for m, t in zip(msgs, truth):
+        pdu = bytes.fromhex(t["pdu"])
+        assert m.sender == pdu[2:8][::-1].hex() and m.payload_hex == pdu[8:].hex()
+        assert m.channel == "37" and m.access_address == "8e89bed6"
