@@ -112,7 +112,6 @@ struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
     uint32_t grid_blocks = 768;      // persistent grid (256 CUs x 3 workgroups)
-    uint32_t ablate = 0;             // dev: skip phases (wrong results) to price them
     DevBuf d_proto, d_tw, d_tw5, d_y;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     int init(uint32_t M);
@@ -128,7 +127,6 @@ struct ZbCtx {
     uint32_t n_slots = 0, threshold = 10, core = 4096, warmup = 1024;
     uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
-    uint32_t ablate = 0;            // dev: skip stages (wrong results) to price them
     uint64_t d_stride = 0;
     bool overflow = false;
     DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft, d_saves;

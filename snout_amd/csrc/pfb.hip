@@ -105,7 +105,7 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
     const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
-    uint64_t plane_stride, uint32_t ablate)
+    uint64_t plane_stride)
 {
     using G = PfbGeom<M>;
     constexpr int T = G::T, M1 = G::M1, M2 = G::M2, D = M / 2, P = 16;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
 
         // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product.
         //      Fused: the last group also produces the 2 extra outputs per parity of the halo.
-        if (!(ablate & 1u) && t < NFIR) {
+        if (t < NFIR) {
             constexpr int NI = FUSED ? 10 : 8;
             const int n_i = (FUSED && grp == NGRP - 1) ? 10 : 8;
             const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
         lds_barrier();        // xs is dead from here: bs reuses its storage
 
         // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}
-        for (int it = t; it < ((ablate & 2u) ? 0 : TH * M2); it += NT) {
+        for (int it = t; it < TH * M2; it += NT) {
             const int m = it % TH, n2 = it / TH;
             cf a[M1], A[M1];
 #pragma unroll
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
 
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
         //      A thread owns two consecutive output times so each global store is 16 bytes.
-        for (int it = t; it < ((ablate & 4u) ? 0 : (TH / 2) * M1); it += NT) {
+        for (int it = t; it < (TH / 2) * M1; it += NT) {
             const int mp = it % (TH / 2), k1 = it / (TH / 2);
             cf Y0[M2], Y1[M2];
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
                 if constexpr (FUSED) {
                     ys[k * YROW + 2 * mp] = make_float2(Y0[k2].re, Y0[k2].im);
                     ys[k * YROW + 2 * mp + 1] = make_float2(v1.re, v1.im);
-                } else if (!(ablate & 8u)) {
+                } else {
                     float2* dst = &y[(uint64_t)k * y_stride + mg];
                     if (mg + 1 < n_out) *reinterpret_cast<float4*>(dst) = make_float4(Y0[k2].re, Y0[k2].im, v1.re, v1.im);
                     else if (mg < n_out) *dst = make_float2(Y0[k2].re, Y0[k2].im);
@@ -284,7 +284,6 @@ int PfbCtx::init(uint32_t M_)
 {
     M = M_;
     if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
-    if (const char* e = getenv("SNOUT_PFB_ABLATE")) ablate = (uint32_t)atoi(e);   // timing experiments only
     if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
     const float* proto = M == 40 ? kPfbProto40 : kPfbProto16;
     const float* tw = M == 40 ? kTw40 : kTw16;
@@ -325,18 +324,18 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
             hipLaunchKernelGGL((pfb_channelize<40, true>), dim3(std::min(n_tiles, grid_blocks)),
                                dim3(PfbGeom<40>::NTF), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
                                d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               (float2*)nullptr, (uint64_t)0, planes16, plane_stride, ablate);
+                               (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
             hipLaunchKernelGGL((pfb_channelize<40, false>), dim3(std::min(n_tiles, grid_blocks)),
                                dim3(PfbGeom<40>::NT), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
                                d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, ablate);
+                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
         hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(std::min(n_tiles, grid_blocks)),
                            dim3(PfbGeom<16>::NT), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
                            d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                           d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, ablate);
+                           d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     }
     SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());

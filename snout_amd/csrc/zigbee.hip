@@ -592,7 +592,6 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
                 uint32_t warmup_)
 {
     n_slots = n_slots_;
-    if (const char* e = getenv("SNOUT_ZB_ABLATE")) ablate = (uint32_t)atoi(e);   // timing experiments only
     threshold = threshold_;
     core = core_;
     warmup = warmup_;
