@@ -93,8 +93,8 @@ class AsyncRecordGather:
     gathered block into pinned host memory; ``finish()`` waits for the oldest started gather and
     returns the records (rank 0) or None.  Two gathers may be in flight, so the exchange of step i
     overlaps the kernels of step i+1.  Every rank sends ``cap`` record slots preceded by a header
-    slot holding its count; ``cap`` is agreed once, at the first start(): twice the largest count of
-    any rank.  ``width`` < 160 gathers only the first ``width`` bytes of each record
+    slot holding its count; ``cap`` is agreed once, at the first start(): 1.25x the largest count of
+    any rank + 1024 (traffic of a capture is stationary; a rank that later exceeds it raises).  ``width`` < 160 gathers only the first ``width`` bytes of each record
     (BTLE records use at most 24 + 42 bytes; the rest is zero by construction).
     """
 
@@ -113,7 +113,8 @@ class AsyncRecordGather:
         self.cap = 0
         self.slots = []
         self.inflight = []
-        self.stream = torch.cuda.Stream(device=device) if self.on_gpu else None
+        # high priority: the short exchange must not queue behind the next segment's kernels
+        self.stream = torch.cuda.Stream(device=device, priority=-1) if self.on_gpu else None
         self.dtype = np.dtype([("sample_index", "<u8"), ("proto", "<u4"), ("channel", "<u2"),
                                ("len", "<u2"), ("crc_ok", "u1"), ("lqi", "u1"), ("pdu_type", "u1"),
                                ("flags", "u1"), ("aux", "<u4"), ("bytes", "u1", (self.width - 24,))])
@@ -122,7 +123,7 @@ class AsyncRecordGather:
         t = self.torch.tensor([n], dtype=self.torch.int64, device=self.device)
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        self.cap = 2 * int(t.item()) + 1024
+        self.cap = int(t.item()) + int(t.item()) // 4 + 1024
         torch = self.torch
         self.slots = []
         for _ in range(2):
@@ -146,7 +147,7 @@ class AsyncRecordGather:
         if n > self.cap:
             # re-agreeing is a collective every rank would have to enter at the same step
             raise RuntimeError(f"rank {self.rank}: {n} records exceed the agreed gather capacity "
-                               f"{self.cap} (2x the largest first-step count)")
+                               f"{self.cap} (1.25x the largest first-step count + 1024)")
         slot = self.slots[self.next]
         self.next ^= 1
         hdr = np.zeros(self.width, dtype=np.uint8)

@@ -52,7 +52,7 @@ def _worker(rank, world, port, q):
         g = sdist.AsyncRecordGather(width=80)
         seq = []
         for step in range(4):
-            k = 2 + step + rank if step < 3 else 700      # 700 > 2*3+1024? no: stays within capacity
+            k = 2 + step + rank if step < 3 else 700      # within the agreed capacity (1.25 * 3 + 1024)
             r = _recs([(0, 37, 10000 * step + 100 * rank + i) for i in range(k)])
             if step == 3:
                 while g.inflight:
