@@ -223,7 +223,7 @@ def main():
                          "kernel": prof.dominant_name, "kernel_ms": k_avg_ms,
                          "algorithmic_bytes": algo_bytes},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
             ns = int(min(args.cpu_samples, n))
             v, n_pk, _ = cpu_baseline(x, ns, passes=3)
             out["cpu_baseline"] = {"value": v, "unit": "Msamples/s", "cores": 1, "kind": "port",
