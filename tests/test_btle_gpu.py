@@ -208,3 +208,36 @@ def test_btle_rx_child_process_drop_in():
         pdu = bytes.fromhex(t["pdu"])
         assert m.sender == pdu[2:8][::-1].hex() and m.payload_hex == pdu[8:].hex()
         assert m.channel == "37" and m.access_address == "8e89bed6"
+
+
+@pytest.mark.parametrize("channel,aa,crc_init", [(0, 0x8E89BED6, 0x555555), (38, 0x8E89BED6, 0x555555),
+                                                   (17, 0x50655D2A, 0x17B3C5), (39, 0xFFFFFFFE, 0x000001)])
+def test_other_channels_and_access_addresses(oracle, channel, aa, crc_init):
+    """`-c`, `-a`, `-k` of the reference's btle_rx call (snout/util/btle.py:63-68) all reach the
+    kernels: whitening seed, correlator word, CRC preset."""
+    from snout_amd.rx import SnoutRx
+    rng = np.random.default_rng(channel)
+    n = 1 << 18
+    x = np.zeros(n, dtype=np.complex64)
+    sent = []
+    pos = 3000
+    while pos + 2500 < n:
+        pdu = synth.btle_random_pdu(rng)
+        wave = synth.gfsk_modulate(synth.btle_air_bits(pdu, channel, aa=aa, crc_init=crc_init))
+        x[pos:pos + wave.size] += wave
+        sent.append(pdu)
+        pos += wave.size + int(rng.integers(500, 9000))
+    x += (0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    with SnoutRx(proto=0, channel=channel, access_addr=aa, crc_init=crc_init) as rx:
+        got = rx.process(x)
+    want, _ = oracle.btle_segment(x, channel=channel, aa=aa, crc_init=crc_init)
+    _same_packets(got, want)
+    assert all(p["channel"] == channel for p in got)
+    if aa == 0xFFFFFFFE:
+        return      # not a legal access address (31 equal bits): it matches one bit early on its own
+                    # preamble, so only GPU == oracle is claimed, not that every packet decodes
+    ok = [bytes(p["bytes"][:p["len"] - 3]) for p in got if p["crc_ok"]]
+    assert ok == sent
+    # the same capture read with the wrong whitening seed / CRC preset yields no good packet
+    with SnoutRx(proto=0, channel=(channel + 1) % 40, access_addr=aa, crc_init=crc_init) as rx:
+        assert not any(p["crc_ok"] for p in rx.process(x))
