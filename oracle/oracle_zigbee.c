@@ -211,91 +211,87 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
 }
 
 /*
- * One lane.  d = discriminator output of the whole segment (n samples).  Returns packets via
- * out/n_out (appending).  soft_z / soft_chips: optional taps (lane-relative, from the lane start).
+ * Lanes.  The clock-recovery loop is a feedback loop, so the segment is cut into
+ * lanes: lane l of a channel covers the core [l core, (l+1) core) and starts its IIR + M&M `warmup`
+ * samples early (IIR state carried in exactly, see below; M&M from its initial state).  A lane
+ * produces every chip whose interpolator window starts before its core end.
+ *
+ * Stitching.  Each chip has the time key T = 128 * (absolute window start) + rint(128 mu)  (the
+ * interpolation instant in 1/128 sample).  Lane 0 owns all its chips.  For lane l+1, the candidates
+ * are its chips whose window start lies in [core_start - 3, core_start + 5]; f0 = the first
+ * candidate with T >= E_l (the chip after the last candidate if none), where E_l = T(last chip of
+ * lane l) + 128, one sample = half a chip period later (E_l = 128 * core_end if lane l produced no
+ * chip).  The discriminator output of O-QPSK/MSK is close to rectangular, so the M&M detector has
+ * a wide dead zone and two loops locked onto the same signal may sit up to a sample apart, where
+ * time alone cannot tell which chip is "the next one".  The chip VALUES decide: for s in (0, -1,
+ * +1) the 48 chips of lane l+1 ending at chip f0+s-1 are compared with the last 48 chips of lane l;
+ * the shift with the most agreements wins (a later shift must be strictly better; a shift whose
+ * 48 chips are not all available is skipped, and no comparison is made if lane l has fewer than 48
+ * chips).  Lane l+1 owns its chips from index f0+s.  The owned chips of consecutive lanes thus
+ * join into ONE chip stream per channel without a repeated or a missing chip.
+ *
+ * Sinks.  gr-ieee802-15-4's packet sink runs over the stitched stream once per lane: it starts
+ * (searching, register cleared) ORACLE_ZB_SINK_WARM chips before the lane's first owned chip (or
+ * at the start of the stream), reports the frames whose first preamble match falls on a chip the
+ * lane owns, and stops when it is idle at or past the next lane's first owned chip.  Sinks that
+ * start at different chips fall into step as soon as both are searching with a full register, so
+ * every frame is reported by exactly one lane.  With core >= n (one lane) this is the reference's
+ * sequential receiver.
  */
-static void run_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t core_len,
-                     uint64_t warmup, unsigned th, uint32_t channel, uint64_t first_index,
-                     uint32_t lane_id, snout_pkt* out, uint64_t cap, uint64_t* n_out,
-                     float* soft_z, float* soft_chips, uint64_t soft_cap, uint64_t* n_chips,
-                     double lp_init)
+#define ORACLE_ZB_SINK_WARM 1024u
+
+typedef struct {
+    uint64_t n_chips;        /* chips produced by the lane's M&M */
+    uint64_t first_owned;    /* index of the first owned chip (<= n_chips) */
+    uint64_t t_last;         /* key of the last chip (valid if n_chips) */
+} lane_chips_t;
+
+/* a5 + a6 of one lane; appends (bit, pos) of ALL its chips to bits/pos/key (capacity ensured by the
+ * caller: (core + warmup) chips at most).  soft_z / soft_chips: optional taps. */
+static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t core_len,
+                        uint64_t warmup, double lp_init, uint8_t* bits, uint64_t* pos, uint64_t* key,
+                        float* soft_z, float* soft_chips, uint64_t soft_cap)
 {
     const uint64_t s0 = core_start > warmup ? core_start - warmup : 0;
     const uint64_t core_end = core_start + core_len;
     const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
     const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
     const float omega_lim = omega_mid * 0.0002f;
-    lane_t s;
-    memset(&s, 0, sizeof(s));
-    s.mu = 0.5f; s.omega = 2.0f; s.last = 0.0f;
-    s.lp = lp_init;       /* IIR state carried in from the samples before the lane (see below) */
-    enter_search(&s);
-    /* z is produced lazily: z_have = number of lane-relative samples filtered so far */
-    float win[8];
-    uint64_t ii = s0;               /* absolute index of the interpolator window start */
-    uint64_t z_next = s0;           /* next sample to run through the IIR */
-    /* ring of filtered samples, big enough for the 8-tap window */
-    float ring[16];
-    uint64_t chips = 0;
-    while (ii + 8 <= n) {
+    double lp = lp_init;
+    float mu = 0.5f, omega = 2.0f, last = 0.0f;
+    float win[8], ring[16];
+    uint64_t ii = s0, z_next = s0, chips = 0;
+    while (ii < core_end && ii + 8 <= n) {
         while (z_next < ii + 8) {
             const float x = d[z_next];
-            s.lp = alpha * (double)x + one_minus * s.lp;
-            const float z = x - (float)s.lp;
+            lp = alpha * (double)x + one_minus * lp;
+            const float z = x - (float)lp;
             ring[z_next & 15] = z;
             if (soft_z && z_next - s0 < soft_cap) soft_z[z_next - s0] = z;
             z_next++;
         }
         for (int k = 0; k < 8; k++) win[k] = ring[(ii + k) & 15];
-        const int imu = (int)rintf(s.mu * 128.0f);
+        const int imu = (int)rintf(mu * 128.0f);
         float acc = 0.0f;
         for (int k = 0; k < 8; k++) acc = fmaf(kMmseTaps[imu][k], win[7 - k], acc);
         const float o = acc;
         if (soft_chips && chips < soft_cap) soft_chips[chips] = o;
+        if (bits) { bits[chips] = o > 0.0f; pos[chips] = ii; key[chips] = ii * 128u + (uint64_t)imu; }
         chips++;
-        const float mm = (s.last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * s.last;
-        s.last = o;
-        s.omega = s.omega + gain_omega * mm;
+        const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+        last = o;
+        omega = omega + gain_omega * mm;
         {
-            const float x = s.omega - omega_mid;
+            const float x = omega - omega_mid;
             const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
-            s.omega = omega_mid + c;
+            omega = omega_mid + c;
         }
-        s.mu = s.mu + s.omega + gain_mu * mm;
-        const float fl = floorf(s.mu);
-        const uint64_t at = ii;
-        ii += (uint64_t)(int)fl;
-        s.mu = s.mu - fl;
-
-        const int was_idle = (s.state == 0 && s.preamble_cnt == 0);
-        const int done = sink_chip(&s, o, at, th);
-        if (was_idle && s.preamble_cnt == 1 && s.trigger >= core_end) break;   /* next lane's */
-        if (done) {
-            if (s.trigger >= core_start && s.trigger < core_end) {
-                if (*n_out < cap) {
-                    snout_pkt* p = &out[*n_out];
-                    memset(p, 0, sizeof(*p));
-                    p->sample_index = first_index + s.trigger;
-                    p->proto = 1;
-                    p->channel = (uint16_t)channel;
-                    p->len = (uint16_t)s.packetlen_cnt;
-                    unsigned scaled = (s.lqi / 8) << 3;
-                    p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
-                    p->aux = lane_id;
-                    memcpy(p->bytes, s.pkt, (size_t)s.packetlen_cnt);
-                    if (s.packetlen_cnt >= 3) {
-                        uint16_t c = oracle_crc16_154(s.pkt, s.packetlen_cnt - 2);
-                        p->crc_ok = (uint8_t)(((c & 0xFF) == s.pkt[s.packetlen_cnt - 2]) &&
-                                              ((c >> 8) == s.pkt[s.packetlen_cnt - 1]));
-                    }
-                }
-                (*n_out)++;
-            }
-            enter_search(&s);
-        }
-        if (s.state == 0 && s.preamble_cnt == 0 && ii >= core_end) break;
+        mu = mu + omega + gain_mu * mm;
+        const float fl = floorf(mu);
+        ii += fl >= 1.0f ? (uint64_t)(int)fl : 1u;     /* 1..3 for finite input */
+        mu = mu - fl;
     }
-    if (n_chips) *n_chips = chips;
+    return chips;
 }
 
 /*
@@ -307,9 +303,11 @@ static void run_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t c
  *   S_j   = sum over the 64 samples of sub-block j of  w[63-k] * d[64 j + k],  w[m] = alpha (1-alpha)^m,
  *           terms summed pairwise: v[i] += v[i+off] for off = 32,16,8,4,2,1   (zero-state response)
  *   L_i   = fold over the sub-blocks of lane block i:  L = D64 * L + S_j
- *   lp_in[i+1] = Dblk_i * lp_in[i] + L_i ,  lp_in[0] = 0
- * where lane block i = [s0_i, s0_{i+1}), s0_i = max(0, i core - warmup), D64 = (1-alpha)^64 and
- * Dblk_i = D64^(sub-blocks of the block), powers formed by repeated multiplication.
+ *   lp_in[l] = fold over the lane blocks i = max(0, l - W) .. l-1, from 0:  lp = Dblk_i * lp + L_i
+ * where lane block i = [s0_i, s0_{i+1}), s0_i = max(0, i core - warmup), D64 = (1-alpha)^64,
+ * Dblk_i = D64^(sub-blocks of the block), powers formed by repeated multiplication, and
+ * W = ceil(2^18 / core) lane blocks: what lies further back has decayed by (1-alpha)^(2^18) < 2^-60
+ * and is dropped, which makes every lane's carry-in an independent, fixed-length computation.
  * Requires core and warmup to be multiples of 64.
  */
 void oracle_zb_iir_tables(double w[64], double* d64)
@@ -349,17 +347,108 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
     double* lp_in = (double*)malloc((n_lanes ? n_lanes : 1) * sizeof(double));
     const double dcore = pow_rep(d64, core / 64u);
     const double dfirst = pow_rep(d64, core > warmup ? (core - warmup) / 64u : 0u);
-    double lp = 0.0;
+    double* L = (double*)malloc((n_lanes ? n_lanes : 1) * sizeof(double));
     for (uint64_t l = 0; l < n_lanes; l++) {
-        lp_in[l] = lp;
         const uint64_t b0 = l == 0 ? 0 : ((uint64_t)l * core - warmup) / 64u;      /* first sub-block */
         const uint64_t b1 = ((uint64_t)(l + 1) * core - warmup) / 64u;             /* one past last   */
-        double L = 0.0;
-        for (uint64_t j = b0; j < b1; j++) L = d64 * L + (j < nsb ? S[j] : 0.0);
-        lp = (l == 0 ? dfirst : dcore) * lp + L;
+        double a = 0.0;
+        for (uint64_t j = b0; j < b1; j++) a = d64 * a + (j < nsb ? S[j] : 0.0);
+        L[l] = a;
     }
+    const uint64_t W = ((1u << 18) + core - 1) / core;
+    for (uint64_t l = 0; l < n_lanes; l++) {
+        double lp = 0.0;
+        for (uint64_t i = l > W ? l - W : 0; i < l; i++) lp = (i == 0 ? dfirst : dcore) * lp + L[i];
+        lp_in[l] = lp;
+    }
+    free(L);
     free(S);
     return lp_in;
+}
+
+/* One channel: lanes -> stitched chip stream -> lane-local sinks. */
+static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint32_t channel,
+                          uint32_t threshold, uint32_t core, uint32_t warmup,
+                          snout_pkt* out, uint64_t cap, uint64_t* n_out)
+{
+    const uint64_t n_lanes = (n + core - 1) / core;
+    double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
+    const uint64_t lane_cap = (uint64_t)core + warmup + 16;
+    uint8_t* lb = (uint8_t*)malloc(lane_cap);
+    uint64_t* lpos = (uint64_t*)malloc(lane_cap * 8);
+    uint64_t* lkey = (uint64_t*)malloc(lane_cap * 8);
+    uint8_t* sb = (uint8_t*)malloc(n + 16);             /* stitched stream: at most one chip per sample */
+    uint64_t* spos = (uint64_t*)malloc((n + 16) * 8);
+    uint64_t* o = (uint64_t*)malloc((n_lanes + 1) * 8); /* stream offset of every lane's first owned chip */
+    uint64_t total = 0;
+    uint64_t E = 0, prev_nc = 0, prev_hist = 0;
+    for (uint64_t l = 0; l < n_lanes; l++) {
+        const uint64_t cs = l * core, ce = cs + core;
+        const uint64_t nc = mm_lane(d, n, cs, core, warmup, lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
+        uint64_t f = 0;
+        if (l > 0) {
+            uint64_t c0 = 0;
+            while (c0 < nc && lpos[c0] + 3 < cs) c0++;              /* first candidate */
+            uint64_t c1 = c0;
+            while (c1 < nc && lpos[c1] <= cs + 5) c1++;             /* one past the last candidate */
+            uint64_t f0 = c0;
+            while (f0 < c1 && lkey[f0] < E) f0++;                   /* first candidate with T >= E */
+            f = f0;
+            if (prev_nc >= 48 && c1 > c0) {
+                const uint64_t c_end = c1 - 1;
+                uint64_t H = 0;                                     /* chips c_end-63 .. c_end, MSB first */
+                for (uint64_t j = (c_end >= 63 ? c_end - 63 : 0); j <= c_end; j++) H = (H << 1) | lb[j];
+                static const int shifts[3] = {0, -1, 1};
+                int best = -1;
+                for (int k = 0; k < 3; k++) {
+                    const int64_t e = (int64_t)f0 + shifts[k] - 1;  /* chip aligned with lane l's last chip */
+                    if (e < 47 || e > (int64_t)c_end) continue;
+                    const uint64_t own = (H >> (c_end - (uint64_t)e)) & 0xFFFFFFFFFFFFull;
+                    const int agree = 48 - __builtin_popcountll(own ^ (prev_hist & 0xFFFFFFFFFFFFull));
+                    if (agree > best) { best = agree; f = (uint64_t)((int64_t)f0 + shifts[k]); }
+                }
+            }
+        }
+        o[l] = total;
+        for (uint64_t j = f; j < nc; j++) { sb[total] = lb[j]; spos[total] = lpos[j]; total++; }
+        E = nc ? lkey[nc - 1] + 128u : ce * 128u;
+        prev_nc = nc;
+        prev_hist = 0;                                              /* last 64 chips of the lane, MSB first */
+        for (uint64_t j = (nc >= 64 ? nc - 64 : 0); j < nc; j++) prev_hist = (prev_hist << 1) | lb[j];
+    }
+    o[n_lanes] = total;
+    for (uint64_t l = 0; l < n_lanes; l++) {
+        lane_t s;
+        memset(&s, 0, sizeof(s));
+        enter_search(&s);
+        for (uint64_t q = o[l] > ORACLE_ZB_SINK_WARM ? o[l] - ORACLE_ZB_SINK_WARM : 0; q < total; q++) {
+            if (s.state == 0 && s.preamble_cnt == 0 && q >= o[l + 1]) break;   /* idle past the lane */
+            const int done = sink_chip(&s, sb[q] ? 1.0f : -1.0f, q, threshold);  /* trigger = chip index */
+            if (done && s.trigger < o[l]) { enter_search(&s); continue; }        /* an earlier lane's frame */
+            if (done) {
+                if (*n_out < cap) {
+                    snout_pkt* p = &out[*n_out];
+                    memset(p, 0, sizeof(*p));
+                    p->sample_index = first_index + spos[s.trigger];
+                    p->proto = 1;
+                    p->channel = (uint16_t)channel;
+                    p->len = (uint16_t)s.packetlen_cnt;
+                    unsigned scaled = (s.lqi / 8) << 3;
+                    p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
+                    p->aux = (uint32_t)l;
+                    memcpy(p->bytes, s.pkt, (size_t)s.packetlen_cnt);
+                    if (s.packetlen_cnt >= 3) {
+                        uint16_t c = oracle_crc16_154(s.pkt, s.packetlen_cnt - 2);
+                        p->crc_ok = (uint8_t)(((c & 0xFF) == s.pkt[s.packetlen_cnt - 2]) &&
+                                              ((c >> 8) == s.pkt[s.packetlen_cnt - 1]));
+                    }
+                }
+                (*n_out)++;
+                enter_search(&s);
+            }
+        }
+    }
+    free(o); free(spos); free(sb); free(lkey); free(lpos); free(lb); free(lp_in);
 }
 
 int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,
@@ -368,16 +457,11 @@ int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uin
 {
     *n_out = 0;
     if (n < 9) return 0;
+    if (core % 64u || warmup % 64u || warmup >= core) return -1;
     float* d = (float*)malloc(n * sizeof(float));
     if (!d) return -3;
     oracle_zb_discrim(iq, n, d);
-    if (core % 64u || warmup % 64u || warmup >= core) { free(d); return -1; }
-    const uint64_t n_lanes = (n + core - 1) / core;
-    double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
-    for (uint64_t l = 0; l < n_lanes; l++)
-        run_lane(d, n, l * core, core, warmup, threshold, channel, first_index, (uint32_t)l, out,
-                 cap, n_out, NULL, NULL, 0, NULL, lp_in[l]);
-    free(lp_in);
+    channel_lanes(d, n, first_index, channel, threshold, core, warmup, out, cap, n_out);
     free(d);
     return *n_out > cap ? -5 : 0;
 }
@@ -387,15 +471,14 @@ int oracle_zigbee_lane_soft(const float* iq, uint64_t n, uint32_t core, uint32_t
                             uint32_t lane, uint32_t threshold, float* z, float* chips,
                             uint64_t cap, uint64_t* n_chips)
 {
+    (void)threshold;
     float* d = (float*)malloc((n ? n : 1) * sizeof(float));
     if (!d) return -3;
     oracle_zb_discrim(iq, n, d);
-    snout_pkt tmp[64];
-    uint64_t cnt = 0;
     const uint64_t n_lanes = (n + core - 1) / core;
     double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
-    run_lane(d, n, (uint64_t)lane * core, core, warmup, threshold, 0, 0, lane, tmp, 64, &cnt, z, chips,
-             cap, n_chips, lane < n_lanes ? lp_in[lane] : 0.0);
+    *n_chips = mm_lane(d, n, (uint64_t)lane * core, core, warmup, lane < n_lanes ? lp_in[lane] : 0.0,
+                       NULL, NULL, NULL, z, chips, cap);
     free(lp_in);
     free(d);
     return 0;

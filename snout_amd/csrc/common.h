@@ -127,9 +127,13 @@ struct ZbCtx {
     uint32_t n_slots = 0, threshold = 10, core = 4096, warmup = 1024;
     uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
-    uint64_t d_stride = 0;
+    uint32_t n_waves = 0, nt = 0, tiles_per_slot = 0;   // waves of 64 lanes, 64-sample tiles per lane
+    uint64_t stream_words = 0;                          // u64 words of one channel's chip stream
     bool overflow = false;
-    DevBuf d_atan, d_mmse, d_slot_channel, d_d, d_stage, d_lane_cnt, d_soft, d_saves;
+    DevBuf d_atan, d_mmse, d_slot_channel, d_stage, d_lane_cnt, d_soft;
+    // discriminator tiles, tile records, per-lane stitch inputs, candidate keys,
+    // first_owned|owned|offs|tsum|slot_total, chip streams
+    DevBuf d_dT, d_TR, d_lane_out, d_cand, d_lane_u32, d_stream;
     DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
     double d64 = 0, dcore = 0, dfirst = 0;
     uint64_t nsb = 0;
@@ -138,7 +142,7 @@ struct ZbCtx {
              uint32_t warmup);
     void destroy();
     int reserve(uint64_t n_channel_samples);
-    int launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int soft_lane);
+    int launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st);
     // discriminator + lanes + ordered compaction into s.d_out / s.d_totals (no host sync)
     int enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
                 ResultSlot& s, bool time_front);

@@ -7,14 +7,17 @@
 //   a6 clock_recovery_mm_ff(2, .000225, .5, .03, .0002)              (serial feedback loop)
 //   a7 ieee802_15_4.packet_sink(10)                                  (serial FSM)
 //
-// The feedback stages are inherently sequential, so parallelism comes from lanes: lane i owns the
-// core [i*core, (i+1)*core) of one channel, starts `warmup` samples early from the initial loop
-// state and runs past its core only to finish a frame whose preamble it found inside the core
-// (the same segmentation the oracle uses).  One wave = 64 lanes; a block is one wave.
+// The clock-recovery loop is sequential, so parallelism comes from lanes: lane i covers the core
+// [i*core, (i+1)*core) of one channel and starts `warmup` samples early (IIR state carried in
+// exactly; M&M from its initial state).  Lanes only produce chips; the owned chips of consecutive
+// lanes are stitched into one chip stream per channel and the packet sink runs on that bit stream
+// (oracle_zigbee.c states the same rules).  One wave = 64 lanes.
 //
-// zb_lanes data flow per 64-sample tile:  HBM d[] --(64 coalesced 256-B row loads)--> LDS ring
-// (transposed, row stride 65 words: bank = (time + lane) mod 32, conflict-free) --> each lane runs
-// IIR, M&M and the sink over its own column.
+//   zb_discrim  HBM-bound; writes the discriminator output as (wave, tile) blocks transposed so
+//               that thread = lane reads its own samples with coalesced loads
+//   zb_mm       IIR + M&M per lane, chips + window advances as 64-bit words per 64-sample tile
+//   zb_stitch / zb_offsets / zb_scatter   first owned chip per lane, stream offsets, bit stream
+//   zb_walk     the sink FSM per lane on the bit stream (per-chip search, 32-chip symbol steps)
 #include "common.h"
 
 namespace snout {
@@ -59,43 +62,92 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     return ang;
 }
 
-// One wave per 64-sample sub-block of one channel.  Besides d[t] the wave emits S_j, the
-// zero-state response of the single-pole IIR to its 64 samples (double, fixed pairwise order), from
-// which zb_iir_carry builds every lane's initial filter state (the "IIR carry-in", see the oracle).
+constexpr uint32_t kTrFields = 9;  // tile record: cw lo/hi, d_lo lo/hi, d_hi lo/hi, nc, cstart, ii_start
+
+// Tile (wave w, tile t) of the transposed discriminator array: element (col, row) = sample 64 t + col
+// of lane 64 w + row, so the 64 lanes of a wave read one coalesced 256-B line per sample.
+__device__ __forceinline__ uint64_t dt_index(uint32_t w, uint32_t nt, uint32_t t, uint32_t col, uint32_t row)
+{
+    return (((uint64_t)w * nt + t) * 64u + col) * 64u + row;
+}
+__device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t, uint32_t field, uint32_t row)
+{
+    return (((uint64_t)w * nt + t) * kTrFields + field) * 64u + row;
+}
+
+// One block per (wave of 64 lanes, 64-sample tile): wave v of the block computes rows 16v..16v+15
+// (row = lane, 64 consecutive samples each, coalesced 512-B reads), the block transposes through
+// LDS and writes the tile as 64 lines of 64 lanes (see dt_index).  The warm-up samples of a lane
+// are the last core samples of the previous one, so they are computed twice (1 + warmup/core reads
+// per sample).  For the rows that lie in their lane's core the wave also emits S_j, the zero-state
+// response of the single-pole IIR to the 64 samples (double, fixed pairwise order), from which
+// zb_iir_fold / zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the oracle).
 __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq, uint64_t n,
-                                                  uint64_t iq_stride, uint32_t n_slots, uint64_t nsb,
+                                                  uint64_t iq_stride, uint32_t lanes_per_slot,
+                                                  uint32_t total_lanes, uint32_t core, uint32_t warmup,
+                                                  uint32_t nt, uint64_t nsb,
                                                   const float* __restrict__ atan_tab,
                                                   const double* __restrict__ iir_w,
-                                                  float* __restrict__ d, uint64_t d_stride,
-                                                  double* __restrict__ S)
+                                                  float* __restrict__ dT, double* __restrict__ S)
 {
     __shared__ float tab[257];
     __shared__ double wts[64];
+    __shared__ float tile[64 * 65];
     for (uint32_t i = threadIdx.x; i < 257; i += 256) tab[i] = atan_tab[i];
     if (threadIdx.x < 64) wts[threadIdx.x] = iir_w[threadIdx.x];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t total = nsb * n_slots;
-    for (uint64_t w = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); w < total;
-         w += (uint64_t)gridDim.x * 4u) {
-        const uint64_t slot = w / nsb, j = w - slot * nsb;
-        const uint64_t t = 64u * j + lane;
-        const float2* x = iq + slot * iq_stride;
+    const uint32_t lane = threadIdx.x & 63u, v = threadIdx.x >> 6;
+    const uint32_t w = blockIdx.x / nt, t = blockIdx.x % nt;
+    for (uint32_t r = v * 16u; r < v * 16u + 16u; r++) {
+        const uint32_t g = w * 64u + r;
         float ang = 0.0f;
-        if (t < n) {
-            const float2 a = x[t];
-            const float2 p = t ? x[t - 1] : make_float2(0.0f, 0.0f);
-            const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
-            const float im = a.y * p.x - a.x * p.y;
-            ang = fast_atan2f_tab(im, re, tab);
-            if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
-            d[slot * d_stride + t] = ang;
-        }
-        double v = wts[63u - lane] * (double)ang;
+        if (g < total_lanes) {
+            const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
+            const uint64_t cs = (uint64_t)li * core;
+            const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
+            const uint64_t a0 = s0 + 64ull * t;             // first sample of the row
+            const uint64_t ta = a0 + lane;
+            const float2* x = iq + (uint64_t)slot * iq_stride;
+            if (ta < n) {
+                const float2 a = x[ta];
+                const float2 p = ta ? x[ta - 1] : make_float2(0.0f, 0.0f);
+                const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
+                const float im = a.y * p.x - a.x * p.y;
+                ang = fast_atan2f_tab(im, re, tab);
+                if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
+            }
+            // sub-block sums only where the row is in the lane's core (every sub-block exactly once)
+            if (a0 >= cs && a0 < cs + core && (a0 >> 6) < nsb) {
+                double sv = wts[63u - lane] * (double)ang;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off);
-        if (lane == 0) S[slot * nsb + j] = v;
+                for (int off = 32; off >= 1; off >>= 1) sv = sv + __shfl_down(sv, off);
+                if (lane == 0) S[(uint64_t)slot * nsb + (a0 >> 6)] = sv;
+            }
+        }
+        tile[r * 65u + lane] = ang;
     }
+    __syncthreads();
+    float* out = dT + ((uint64_t)w * nt + t) * 4096u;
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; k++) {
+        const uint32_t idx = k * 256u + threadIdx.x;        // = col * 64 + row
+        out[idx] = tile[(idx & 63u) * 65u + (idx >> 6)];
+    }
+}
+
+// Test tap: channel-ordered discriminator output of one slot, gathered from the core tiles.
+__global__ __launch_bounds__(256) void zb_gather_d(const float* __restrict__ dT, uint64_t n, uint32_t slot,
+                                                   uint32_t lanes_per_slot, uint32_t core, uint32_t warmup,
+                                                   uint32_t nt, float* __restrict__ out, uint64_t cap)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= n || t >= cap) return;
+    const uint32_t li = (uint32_t)(t / core);
+    const uint64_t cs = (uint64_t)li * core;
+    const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
+    const uint32_t rel = (uint32_t)(t - s0);
+    const uint32_t g = slot * lanes_per_slot + li;
+    out[t] = dT[dt_index(g >> 6, nt, rel >> 6, rel & 63u, g & 63u)];
 }
 
 // Lane block i = [s0_i, s0_{i+1}): fold its sub-block sums, L = D64 L + S_j (one thread per lane).
@@ -115,45 +167,329 @@ __global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S,
     Lblk[g] = L;
 }
 
-// lp_in[i+1] = Dblk_i lp_in[i] + L_i along the lanes of a channel: one wave per channel walks the
-// lanes 64 at a time (coalesced load of L, then the sequential recurrence with v_readlane).
-__global__ __launch_bounds__(64) void zb_iir_scan(const double* __restrict__ Lblk, uint32_t lanes_per_slot,
-                                                  uint32_t n_slots, double dfirst, double dcore,
-                                                  double* __restrict__ lp_in)
+// lp_in[l] = fold of the W = ceil(2^18 / core) lane blocks before lane l, from 0 (older samples have
+// decayed below 2^-60; see the oracle): one thread per lane, no dependence between lanes.
+__global__ __launch_bounds__(256) void zb_iir_scan(const double* __restrict__ Lblk, uint32_t lanes_per_slot,
+                                                  uint32_t total_lanes, uint32_t window, double dfirst,
+                                                  double dcore, double* __restrict__ lp_in)
 {
-    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
-    if (slot >= n_slots) return;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_lanes) return;
+    const uint32_t li = g % lanes_per_slot;
+    const double* L = Lblk + (g - li);
     double lp = 0.0;
-    double nxt = lane < lanes_per_slot ? Lblk[slot * lanes_per_slot + lane] : 0.0;
-    for (uint32_t l0 = 0; l0 < lanes_per_slot; l0 += 64u) {
-        const uint32_t g = slot * lanes_per_slot + l0 + lane;
-        const double v = nxt;
-        nxt = (l0 + 64u + lane < lanes_per_slot) ? Lblk[g + 64u] : 0.0;     // in flight during the chain
-        double mine = 0.0;
-#pragma unroll 8
-        for (uint32_t i = 0; i < 64u; i++) {
-            if (lane == i) mine = lp;                          // state before lane l0+i
-            const double Li = __shfl(v, (int)i);
-            lp = ((l0 + i) == 0u ? dfirst : dcore) * lp + Li;
+    for (uint32_t i = li > window ? li - window : 0u; i < li; i++) lp = (i == 0u ? dfirst : dcore) * lp + L[i];
+    lp_in[g] = lp;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5-a6: lanes (IIR + Mueller & Mueller), chips out.
+// ---------------------------------------------------------------------------------------------
+constexpr int kZRow = 73;          // per-lane z buffer: 8 samples of history + one 64-sample tile, odd stride
+constexpr int kTapStride = 131;    // tap-major MMSE table in LDS: tapsT[k * 131 + imu]
+constexpr uint32_t kMaxCand = 12;
+constexpr uint32_t kSinkWarmChips = 1024;   // sink warm-up on the stitched stream (ORACLE_ZB_SINK_WARM)
+
+// What a lane hands to the stitcher (see oracle_zigbee.c "Stitching").
+struct ZbLaneOut {
+    uint32_t nc;            // chips produced
+    uint32_t t_last;        // lane-relative key of the last chip: 128 * window start + rint(128 mu)
+    uint32_t c0;            // index of the first candidate chip (window start in [core_start-3, core_start+5])
+    uint32_t cand_n;
+    uint64_t hist_end;      // the last 64 chips, most recent in bit 0
+    uint64_t hist_cand;     // the 64 chips ending at the last candidate
+};
+
+// One wave = 64 lanes, thread = lane.  Per 64-sample tile: the thread's own 64 discriminator
+// samples arrive in registers (prefetched during the previous tile), the fp64 IIR turns them into
+// z (LDS row of the lane: 8 samples of history + the tile), then the M&M steps whose window starts
+// inside the tile run, shifting hard decisions and window advances into 64-bit words that are
+// stored as the tile's record.  No sink here: chips go to the stitched stream (zb_scatter) and the
+// sinks run on bits (zb_walk).
+template <bool TAP>
+__global__ __launch_bounds__(64) void zb_mm(
+    const float* __restrict__ dT, uint64_t n, uint32_t nt, uint32_t lanes_per_slot, uint32_t total_lanes,
+    uint32_t core, uint32_t warmup, const float* __restrict__ mmse, const double* __restrict__ lp_in,
+    uint32_t* __restrict__ TR, ZbLaneOut* __restrict__ lane_out, uint32_t* __restrict__ cand_keys,
+    float* __restrict__ soft_z, float* __restrict__ soft_chips, uint32_t soft_lane, uint32_t soft_cap,
+    uint32_t* __restrict__ soft_n)
+{
+    __shared__ float zb[64 * kZRow];
+    __shared__ float tapsT[8 * kTapStride];
+    const uint32_t l = threadIdx.x, w = blockIdx.x;
+    for (uint32_t i = l; i < 129u * 8u; i += 64u) tapsT[(i & 7u) * kTapStride + (i >> 3)] = mmse[i];
+    const uint32_t g = w * 64u + l;
+    const bool active = g < total_lanes;
+    const uint32_t li = active ? g % lanes_per_slot : 0u;
+    const uint64_t core_start = (uint64_t)li * core;
+    const uint64_t s0 = core_start > warmup ? core_start - warmup : 0ull;
+    const uint32_t rcs = (uint32_t)(core_start - s0);       // lane-relative core start
+    const uint32_t rce = rcs + core;
+    const uint32_t avail = active && n > s0 ? (uint32_t)((n - s0) < (uint64_t)(rce + 64u) ? (n - s0) : (rce + 64u)) : 0u;
+    const uint32_t tb = warmup >> 6;                        // the tile that holds the stitch candidates
+    __syncthreads();
+
+    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+    const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
+    const float omega_lim = omega_mid * 0.0002f;
+    double lp = active ? lp_in[g] : 0.0;
+    float mu = 0.5f, omega = 2.0f, last = 0.0f;
+    uint32_t ii = 0, n_chips = 0, t_last = 0, c0 = 0, cand_n = 0;
+    uint64_t hist = 0, hist_cand = 0;
+    const bool tap = TAP && active && g == soft_lane && soft_chips != nullptr;
+    float* zrow = &zb[l * kZRow];
+    float zl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) zl[k] = 0.0f;
+
+    float pre[64];
+#pragma unroll
+    for (uint32_t col = 0; col < 64u; col++) pre[col] = dT[dt_index(w, nt, 0u, col, l)];
+
+    for (uint32_t tile = 0; tile < nt; tile++) {
+        const uint32_t r0 = tile * 64u;
+        // ---- a5: DC removal of this tile (sequential fp64 recurrence); the last tile only feeds the
+        //      windows that start before the core end, 8 samples are enough
+        const uint32_t nz = (tile + 1u == nt) ? 8u : 64u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) zrow[k] = zl[k];
+#pragma unroll
+        for (uint32_t q = 0; q < 64u; q += 8u) {
+            if (q < nz) {
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    const float x = pre[q + k];
+                    lp = alpha * (double)x + one_minus * lp;
+                    const float z = x - (float)lp;
+                    zrow[8u + q + k] = z;
+                    zl[k] = z;
+                    if constexpr (TAP) { if (tap && soft_z && r0 + q + k < soft_cap) soft_z[r0 + q + k] = z; }
+                }
+            }
         }
-        if (l0 + lane < lanes_per_slot) lp_in[g] = mine;
+        // ---- next tile's samples: in flight during the M&M steps
+        if (tile + 1u < nt) {
+#pragma unroll
+            for (uint32_t col = 0; col < 64u; col++) pre[col] = dT[dt_index(w, nt, tile + 1u, col, l)];
+        }
+        // ---- a6: the M&M steps whose window starts in this tile
+        const uint32_t staged = r0 + nz;
+        const uint32_t hi = staged < avail ? staged : avail;
+        const uint32_t cstart = n_chips, ii_start = ii;
+        uint64_t d_lo = 0, d_hi = 0;
+        uint32_t nc = 0;
+        const bool cand_tile = tile == tb && li > 0u;
+        while (ii < rce && ii + 8u <= hi) {
+            const int imu = (int)rintf(mu * 128.0f);
+            const float* tp = &tapsT[imu];
+            const float* wv = &zrow[ii + 8u - r0];                // 8 consecutive samples
+            float acc = 0.0f;
+            acc = __builtin_fmaf(tp[0 * kTapStride], wv[7], acc);
+            acc = __builtin_fmaf(tp[1 * kTapStride], wv[6], acc);
+            acc = __builtin_fmaf(tp[2 * kTapStride], wv[5], acc);
+            acc = __builtin_fmaf(tp[3 * kTapStride], wv[4], acc);
+            acc = __builtin_fmaf(tp[4 * kTapStride], wv[3], acc);
+            acc = __builtin_fmaf(tp[5 * kTapStride], wv[2], acc);
+            acc = __builtin_fmaf(tp[6 * kTapStride], wv[1], acc);
+            acc = __builtin_fmaf(tp[7 * kTapStride], wv[0], acc);
+            const float o = acc;
+            if constexpr (TAP) { if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o; }
+            hist = (hist << 1) | (o > 0.0f ? 1ull : 0ull);
+            t_last = ii * 128u + (uint32_t)imu;
+            if (cand_tile && ii + 3u - rcs <= 8u && cand_n < kMaxCand) {
+                if (cand_n == 0u) c0 = n_chips + nc;
+                cand_keys[(size_t)g * kMaxCand + cand_n] = t_last;
+                cand_n++;
+                hist_cand = hist;
+            }
+            const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+            last = o;
+            omega = omega + gain_omega * mm;
+            {
+                const float x = omega - omega_mid;
+                const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+                omega = omega_mid + c;
+            }
+            mu = mu + omega + gain_mu * mm;
+            const float fl = floorf(mu);
+            const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
+            ii += step;
+            mu = mu - fl;
+            d_lo = (d_lo << 1) | ((step - 1u) & 1u);
+            d_hi = (d_hi << 1) | (((step - 1u) >> 1) & 1u);
+            nc++;
+        }
+        n_chips += nc;
+        // ---- tile record: chip c of the tile at bit 63 - c
+        {
+            const uint32_t sh = 64u - nc;
+            const uint64_t cw = nc ? hist << sh : 0ull;
+            const uint64_t dl = nc ? d_lo << sh : 0ull, dh = nc ? d_hi << sh : 0ull;
+            TR[tr_index(w, nt, tile, 0, l)] = (uint32_t)cw;
+            TR[tr_index(w, nt, tile, 1, l)] = (uint32_t)(cw >> 32);
+            TR[tr_index(w, nt, tile, 2, l)] = (uint32_t)dl;
+            TR[tr_index(w, nt, tile, 3, l)] = (uint32_t)(dl >> 32);
+            TR[tr_index(w, nt, tile, 4, l)] = (uint32_t)dh;
+            TR[tr_index(w, nt, tile, 5, l)] = (uint32_t)(dh >> 32);
+            TR[tr_index(w, nt, tile, 6, l)] = nc;
+            TR[tr_index(w, nt, tile, 7, l)] = cstart;
+            TR[tr_index(w, nt, tile, 8, l)] = ii_start;
+        }
+    }
+    if (active) {
+        ZbLaneOut lo;
+        lo.nc = n_chips; lo.t_last = t_last; lo.c0 = cand_n ? c0 : n_chips; lo.cand_n = cand_n;
+        lo.hist_end = hist; lo.hist_cand = hist_cand;
+        lane_out[g] = lo;
+    }
+    if constexpr (TAP) { if (tap && soft_n) *soft_n = n_chips; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stitching: first owned chip of every lane (oracle_zigbee.c "Stitching"), owned counts and their
+// per-channel exclusive scan (stream offset of every lane), 1024 lanes per block.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t x, uint32_t* lds4)
+{
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) x += __shfl_down(x, dlt);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__global__ __launch_bounds__(256) void zb_stitch(const ZbLaneOut* __restrict__ lane_out,
+                                                 const uint32_t* __restrict__ cand_keys,
+                                                 uint32_t lanes_per_slot, uint32_t core, uint32_t warmup,
+                                                 uint32_t tiles_per_slot, uint32_t* __restrict__ first_owned,
+                                                 uint32_t* __restrict__ owned, uint32_t* __restrict__ tsum)
+{
+    __shared__ uint32_t lds4[4];
+    const uint32_t slot = blockIdx.y, tile = blockIdx.x;
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t li = tile * kScanTile + threadIdx.x * 4u + k;
+        if (li >= lanes_per_slot) continue;
+        const uint32_t g = slot * lanes_per_slot + li;
+        const ZbLaneOut me = lane_out[g];
+        uint32_t f = 0;
+        if (li > 0u) {
+            const ZbLaneOut pv = lane_out[g - 1u];
+            const uint64_t cs = (uint64_t)li * core;
+            const uint64_t s0 = cs - warmup;                          // li >= 1 and warmup < core
+            const uint64_t ps0 = (li - 1u) ? cs - core - warmup : 0ull;
+            const uint64_t E = pv.nc ? ps0 * 128u + pv.t_last + 128u : cs * 128u;
+            uint32_t f0 = me.c0;
+            for (uint32_t j = 0; j < me.cand_n; j++) {
+                if (s0 * 128u + cand_keys[(size_t)g * kMaxCand + j] < E) f0++; else break;
+            }
+            f = f0;
+            if (pv.nc >= 48u && me.cand_n > 0u) {
+                const uint32_t c_end = me.c0 + me.cand_n - 1u;
+                const uint64_t m48 = 0xFFFFFFFFFFFFull;
+                int best = -1;
+#pragma unroll
+                for (int k2 = 0; k2 < 3; k2++) {
+                    const int sft = k2 == 0 ? 0 : (k2 == 1 ? -1 : 1);
+                    const int64_t e = (int64_t)f0 + sft - 1;
+                    if (e < 47 || e > (int64_t)c_end) continue;
+                    const uint64_t own = (me.hist_cand >> (c_end - (uint32_t)e)) & m48;
+                    const int agree = 48 - __popcll(own ^ (pv.hist_end & m48));
+                    if (agree > best) { best = agree; f = (uint32_t)((int64_t)f0 + sft); }
+                }
+            }
+        }
+        if (f > me.nc) f = me.nc;
+        first_owned[g] = f;
+        owned[g] = me.nc - f;
+        s += me.nc - f;
+    }
+    const uint32_t tot = block_sum_256(s, lds4);
+    if (threadIdx.x == 0) tsum[slot * tiles_per_slot + tile] = tot;
+}
+
+__global__ __launch_bounds__(256) void zb_offsets(const uint32_t* __restrict__ owned,
+                                                  const uint32_t* __restrict__ tsum, uint32_t lanes_per_slot,
+                                                  uint32_t tiles_per_slot, uint32_t* __restrict__ offs,
+                                                  uint32_t* __restrict__ slot_total)
+{
+    __shared__ uint32_t lds4[4];
+    const uint32_t slot = blockIdx.y, tile = blockIdx.x;
+    uint32_t x = 0;
+    for (uint32_t i = threadIdx.x; i < tile; i += 256u) x += tsum[slot * tiles_per_slot + i];
+    const uint32_t base = block_sum_256(x, lds4);
+    uint32_t c[4], s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t li = tile * kScanTile + threadIdx.x * 4u + k;
+        c[k] = li < lanes_per_slot ? owned[slot * lanes_per_slot + li] : 0u;
+        s += c[k];
+    }
+    uint32_t inc = s;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const uint32_t t = __shfl_up(inc, dlt);
+        if ((int)lane >= dlt) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds4[wv] = inc;
+    __syncthreads();
+    uint32_t off = base + inc - s;
+    for (uint32_t q = 0; q < wv; q++) off += lds4[q];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t li = tile * kScanTile + threadIdx.x * 4u + k;
+        if (li < lanes_per_slot) offs[slot * lanes_per_slot + li] = off;
+        off += c[k];
+    }
+    if (tile + 1u == tiles_per_slot && threadIdx.x == 255u) slot_total[slot] = off;
+}
+
+// Owned chips of every lane -> the channel's chip stream (chip q at bit 63 - q % 64 of word q / 64).
+// Thread = lane; the tile records of 64 consecutive lanes are read as coalesced lines.
+__global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ TR, uint32_t nt,
+                                                  uint32_t lanes_per_slot, uint32_t total_lanes,
+                                                  const uint32_t* __restrict__ first_owned,
+                                                  const uint32_t* __restrict__ offs,
+                                                  unsigned long long* __restrict__ stream, uint64_t stream_words)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_lanes) return;
+    const uint32_t w = g >> 6, row = g & 63u;
+    const uint32_t slot = g / lanes_per_slot;
+    const uint32_t f = first_owned[g], o = offs[g];
+    unsigned long long* sw = stream + (uint64_t)slot * stream_words;
+    uint32_t c = 0;
+    for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t nc = TR[tr_index(w, nt, t, 6, row)];
+        if (nc == 0u) continue;
+        const uint32_t lo = f > c ? f : c;
+        if (lo < c + nc) {
+            const uint64_t cw = (uint64_t)TR[tr_index(w, nt, t, 0, row)] |
+                                ((uint64_t)TR[tr_index(w, nt, t, 1, row)] << 32);
+            const uint32_t skip = lo - c, cnt = nc - skip;
+            const uint64_t bits = (cw << skip) & (~0ull << (64u - cnt));
+            const uint32_t q = o + (lo - f);
+            const uint32_t sh = q & 63u;
+            atomicOr(&sw[q >> 6], bits >> sh);
+            if (sh + cnt > 64u) atomicOr(&sw[(q >> 6) + 1u], bits << (64u - sh));
+        }
+        c += nc;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// a5-a7: lanes.
+// a7: the packet sink on the stitched chip stream, one thread per lane.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRingLen = 128;      // two 64-sample tiles of history per lane
-constexpr int kRingStride = 137;   // per-lane row: 128 + 8 mirrored entries, odd -> bank = (lane + time) mod 32
-// ring[lane * kRingStride + (t & 127)] holds sample t of the lane; entries 128..135 mirror 0..7 so an
-// 8-sample window never wraps and is read with immediate offsets from one address.
-
 struct SinkState {
     int state;          // 0 search, 1 have_sync, 2 have_header
     uint32_t shift;
     int preamble_cnt, chip_cnt, packet_byte, byte_index, packetlen, packetlen_cnt, payload_cnt;
     uint32_t lqi, lqi_cnt;
-    uint32_t trigger;   // lane-relative sample index of the first preamble match
+    uint32_t trigger;   // stream index of the chip that completed the first preamble match
     uint32_t c0, c1, c2;   // running FCS: after all bytes, one byte ago, two bytes ago
     uint32_t b_prev, b_last;   // the last two PSDU bytes
 };
@@ -196,22 +532,9 @@ __device__ __forceinline__ uint32_t crc16_step(uint32_t c, uint32_t byte)
     return c;
 }
 
-// The packet sink, split by what a chip can trigger.
-//  * searching (state 0, preamble_cnt == 0): every chip is tested against symbol 0;
-//  * otherwise chips are only counted until the next symbol boundary (32 chips), where
-//    sink_symbol() does the work.  The lane loop therefore shifts whole runs of chips in at once.
-// Together they are exactly gr-ieee802-15-4's per-chip state machine.
-__device__ __forceinline__ void sink_search_chip(SinkState& s, uint32_t bit, uint32_t at, uint32_t th)
-{
-    s.shift = (s.shift << 1) | bit;
-    if (chip_dist(s.shift, kChipMap[0]) < th) {
-        s.preamble_cnt = 1;         // chip_cnt stays 0: the boundary is 32 chips after this one
-        s.trigger = at;
-    }
-}
-
-// Called when chip_cnt reached 32 (s.shift holds the symbol's chips).  Returns true when a frame
-// completed (caller publishes, then enter_search).
+// Called at a symbol boundary (32 chips after the previous one; s.shift holds the symbol's chips).
+// Returns true when a frame completed (caller publishes, then enter_search).  Together with the
+// per-chip search in zb_walk this is gr-ieee802-15-4's per-chip state machine.
 __device__ __forceinline__ bool sink_symbol(SinkState& s, uint32_t th, uint8_t* __restrict__ pkt_bytes)
 {
     s.chip_cnt = 0;
@@ -258,264 +581,171 @@ __device__ __forceinline__ bool sink_symbol(SinkState& s, uint32_t th, uint8_t* 
     return s.payload_cnt >= s.packetlen;
 }
 
-// Continuation of a lane that reached the end of its core inside a frame it owns.
-struct ZbLaneSave {
-    double lp;
-    float mu, omega, last;
-    uint32_t g, ii, znext, n_pk, n_chips;
-    SinkState s;
-    float zhist[16];        // z[znext-16 .. znext)
+// Full-register preamble matches of the whole stream, all chips in parallel: bit (63 - q % 64) of
+// match[q / 64] = popcount((window of 32 chips ending at q) ^ symbol 0, masked) < threshold, i.e. what
+// the sink's search test yields once at least 32 chips have been shifted in since it was cleared.
+__global__ __launch_bounds__(256) void zb_match(const unsigned long long* __restrict__ stream,
+                                                uint64_t stream_words, const uint32_t* __restrict__ slot_total,
+                                                uint32_t th, unsigned long long* __restrict__ match)
+{
+    const uint32_t slot = blockIdx.y;
+    const uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (wi >= stream_words || wi * 64u >= (uint64_t)slot_total[slot]) return;
+    const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
+    const uint64_t cur = sw[wi], prev = wi ? sw[wi - 1u] : 0ull;
+    const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
+    uint64_t m = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 64u; i++) {
+        uint64_t x = cur >> (63u - i);
+        if (i < 31u) x |= prev << (i + 1u);
+        const uint32_t dist = (uint32_t)__popc(((uint32_t)x & 0x7FFFFFFEu) ^ sym0);
+        m |= (uint64_t)(dist < th) << (63u - i);
+    }
+    match[(uint64_t)slot * stream_words + wi] = m;
+}
+
+// Sequential reader of one channel's chip stream: the sink only moves forward, so the words around
+// the cursor stay in registers and the next two are always in flight.
+struct ChipReader {
+    const unsigned long long* sw;
+    uint32_t wi;                    // index of `cur`
+    uint64_t prev, cur, n1, n2;
+    __device__ __forceinline__ void open(const unsigned long long* s, uint32_t q)
+    {
+        sw = s; wi = q >> 6;
+        prev = wi ? sw[wi - 1u] : 0ull; cur = sw[wi]; n1 = sw[wi + 1u]; n2 = sw[wi + 2u];
+    }
+    __device__ __forceinline__ void seek(uint32_t q)        // q >= 64 * wi
+    {
+        if ((q >> 6) > wi + 2u) { open(sw, q); return; }     // far jump: four independent loads
+        while (wi < (q >> 6)) { prev = cur; cur = n1; n1 = n2; wi++; n2 = sw[wi + 2u]; }
+    }
+    __device__ __forceinline__ uint32_t bit(uint32_t q) const { return (uint32_t)(cur >> (63u - (q & 63u))) & 1u; }
+    // the 32 chips ending at chip q (chip q in bit 0); q >= 31, in the current word
+    __device__ __forceinline__ uint32_t window32(uint32_t q) const
+    {
+        const uint32_t sh = 63u - (q & 63u);
+        uint64_t x = cur >> sh;
+        if (sh > 32u) x |= prev << (64u - sh);
+        return (uint32_t)x;
+    }
 };
 
-// Two passes.  RESUME = false: every lane runs from its warm-up start to the end of its core; a
-// lane that is inside a frame it owns at that point saves its loop state and stops, so no wave is
-// held back by its longest frame.  RESUME = true: the saved lanes (compacted, dense waves) finish
-// their frames.  Both passes perform exactly the operations of the single sequential lane.
-template <bool RESUME>
-__global__ __launch_bounds__(64) void zb_lanes(
-    const float* __restrict__ d, uint64_t n, uint64_t d_stride, uint32_t lanes_per_slot,
-    uint32_t total_lanes, uint32_t core, uint32_t warmup, uint32_t th,
-    const uint16_t* __restrict__ slot_channel, uint64_t first_index,
-    const float* __restrict__ mmse, snout_pkt* __restrict__ stage, uint32_t K,
-    uint32_t* __restrict__ lane_cnt, const double* __restrict__ lp_in,
-    ZbLaneSave* __restrict__ saves, uint32_t* __restrict__ n_saves,
-    float* __restrict__ soft_z, float* __restrict__ soft_chips,
-    uint32_t soft_lane, uint32_t soft_cap, uint32_t* __restrict__ soft_n)
+__global__ __launch_bounds__(256) void zb_walk(
+    const unsigned long long* __restrict__ stream, const unsigned long long* __restrict__ match,
+    uint64_t stream_words, const uint32_t* __restrict__ offs,
+    const uint32_t* __restrict__ first_owned, const uint32_t* __restrict__ slot_total,
+    const uint32_t* __restrict__ TR, uint32_t nt, uint32_t lanes_per_slot, uint32_t total_lanes,
+    uint32_t core, uint32_t warmup, uint32_t th, const uint16_t* __restrict__ slot_channel,
+    uint64_t first_index, snout_pkt* __restrict__ stage, uint32_t K, uint32_t* __restrict__ lane_cnt)
 {
-    __shared__ float ring[64 * kRingStride];
-    __shared__ __attribute__((aligned(16))) float taps[129 * 8];
-    const uint32_t l = threadIdx.x;
-    for (uint32_t i = l; i < 129u * 8u; i += 64u) taps[i] = mmse[i];
-    const uint32_t job = blockIdx.x * 64u + l;
-    uint32_t n_jobs = total_lanes;
-    if constexpr (RESUME) {
-        n_jobs = *n_saves;
-        if (blockIdx.x * 64u >= n_jobs) return;          // whole wave beyond the job list
-    }
-    const bool active = job < n_jobs;
-    ZbLaneSave sv;
-    if constexpr (RESUME) { if (active) sv = saves[job]; }
-    const uint32_t g = RESUME ? (active ? sv.g : 0u) : job;
-    const uint32_t slot = active ? g / lanes_per_slot : 0u;
-    const uint32_t li = active ? g % lanes_per_slot : 0u;
-    const uint64_t core_start = (uint64_t)li * core;
-    const uint64_t s0 = core_start > warmup ? core_start - warmup : 0ull;
-    // lane-relative coordinates (r = t - s0); a resumed lane shifts its origin to 64 samples before
-    // the first sample it still has to filter, so every lane of the wave starts at tile 0
-    const uint32_t origin = RESUME ? (active ? sv.znext - 64u : 0u) : 0u;
-    const uint32_t rel_core_start = (uint32_t)(core_start - s0);
-    const uint32_t rel_core_end = rel_core_start + core;            // in unshifted coordinates
-    const uint64_t avail64 = active && n > s0 + origin ? n - s0 - origin : 0ull;
-    // a frame that starts before the core end is over within 17 024 + a few samples
-    const uint64_t lane_max = (uint64_t)rel_core_end + 20000u - origin;
-    const uint32_t avail = (uint32_t)(avail64 < lane_max ? avail64 : lane_max);
-    const uint64_t base = (uint64_t)slot * d_stride + s0 + origin;  // offset of r = 0 in d
-    __syncthreads();
-
-    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
-    const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
-    const float omega_lim = omega_mid * 0.0002f;
-    double lp = (!RESUME && active) ? lp_in[g] : 0.0;    // IIR state carried in from before the lane
-    float mu = 0.5f, omega = 2.0f, last = 0.0f;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_lanes) return;
+    const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
+    const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
+    const unsigned long long* mt = match + (uint64_t)slot * stream_words;
+    const uint32_t total = slot_total[slot];
+    const uint32_t own0 = offs[g];
+    const uint32_t own1 = li + 1u < lanes_per_slot ? offs[g + 1u] : total;
     SinkState s;
     enter_search(s);
     s.byte_index = s.packetlen = s.packetlen_cnt = s.payload_cnt = 0;
     s.lqi = s.lqi_cnt = 0; s.trigger = 0; s.c0 = s.c1 = s.c2 = 0; s.b_prev = s.b_last = 0;
-    uint32_t ii = 0;            // window start
-    uint32_t znext = 0;         // first sample not yet through the IIR
-    uint32_t n_pk = 0, n_chips = 0;
-    if constexpr (RESUME) {
-        if (active) {
-            lp = sv.lp; mu = sv.mu; omega = sv.omega; last = sv.last; s = sv.s;
-            ii = sv.ii - origin; znext = 64u; n_pk = sv.n_pk; n_chips = sv.n_chips;
+    uint32_t n_pk = 0;
+    uint32_t q = own0 > kSinkWarmChips ? own0 - kSinkWarmChips : 0u;
+    ChipReader rd;
+    rd.open(sw, q);
+    while (q < total) {
+        if (s.state == 0 && s.preamble_cnt == 0) {
+            // searching: one test per chip
+            if (q >= own1) break;                       // idle at or past the next lane's first chip
+            // The register was cleared at chip q.  While fewer than 32 chips are in, the test sees a
+            // zero-filled register: 31 explicit tests on the 64 chips that start at q ...
+            const uint32_t lim = own1 < total ? own1 : total;
+            rd.seek(q);
+            const uint32_t bo = q & 63u;
+            const uint64_t x64 = bo ? (rd.cur << bo) | (rd.n1 >> (64u - bo)) : rd.cur;
+            const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
+            uint32_t pm = 0;                            // bit k: match after chip q + k, k = 0..30
+#pragma unroll
+            for (uint32_t k = 0; k < 31u; k++) {
+                const uint32_t reg = (uint32_t)(x64 >> (63u - k));
+                pm |= (uint32_t)((uint32_t)__popc((reg & 0x7FFFFFFEu) ^ sym0) < th) << k;
+            }
+            bool hit = false;
+            uint32_t qh = 0;
+            if (pm) {
+                qh = q + (uint32_t)__ffs((int)pm) - 1u;
+                hit = qh < lim;
+            }
+            if (!pm) {
+                // ... then the precomputed full-register matches, a word at a time
+                uint32_t qs = q + 31u;
+                while (qs < lim) {
+                    const uint64_t mw = mt[qs >> 6] & (~0ull >> (qs & 63u));
+                    if (mw) { qh = (qs & ~63u) + (uint32_t)__clzll((long long)mw); hit = qh < lim; break; }
+                    qs = (qs & ~63u) + 64u;
+                }
+            }
+            if (hit) {
+                q = qh + 1u;
+                rd.seek(q);
+            }
+            if (!hit) break;                            // ran to the end of the lane (or of the stream) idle
+            s.preamble_cnt = 1;                         // chip_cnt stays 0: the boundary is 32 chips on
+            s.trigger = q - 1u;
+            continue;
+        }
+        // inside a (candidate) frame: jump to the next symbol boundary
+        const uint32_t qb = q + 31u;                    // q is the first chip of the symbol
+        if (qb >= total) break;                         // the stream ends inside the frame
+        rd.seek(qb);
+        s.shift = rd.window32(qb);
+        uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
+        const bool fin = sink_symbol(s, th, pb);
+        q = qb + 1u;
+        if (fin) {
+            if (s.trigger >= own0) {                    // owned (the search never starts a frame past own1)
+                if (n_pk < K) {
+                    // window start of the trigger chip: chip j of this lane, found in its tile records
+                    const uint32_t j = first_owned[g] + (s.trigger - own0);
+                    const uint32_t w = g >> 6, row = g & 63u;
+                    uint32_t lo = 0, hi2 = nt;          // last tile with cstart <= j and nc > 0 reaching j
+                    while (hi2 - lo > 1u) {
+                        const uint32_t mid = (lo + hi2) >> 1;
+                        if (TR[tr_index(w, nt, mid, 7, row)] <= j) lo = mid; else hi2 = mid;
+                    }
+                    const uint32_t i = j - TR[tr_index(w, nt, lo, 7, row)];
+                    const uint64_t dl = (uint64_t)TR[tr_index(w, nt, lo, 2, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 3, row)] << 32);
+                    const uint64_t dh = (uint64_t)TR[tr_index(w, nt, lo, 4, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 5, row)] << 32);
+                    const uint64_t top = i ? ~0ull << (64u - i) : 0ull;
+                    const uint32_t rel = TR[tr_index(w, nt, lo, 8, row)] + i + (uint32_t)__popcll(dl & top) +
+                                         2u * (uint32_t)__popcll(dh & top);
+                    const uint64_t cs = (uint64_t)li * core;
+                    const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
+                    snout_pkt* p = &stage[(size_t)g * K + n_pk];
+                    const uint32_t len = (uint32_t)s.packetlen_cnt;
+                    for (uint32_t b = len; b < 136u; b++) p->bytes[b] = 0;
+                    p->sample_index = first_index + s0 + rel;
+                    p->proto = SNOUT_PROTO_ZIGBEE;
+                    p->channel = slot_channel[slot];
+                    p->len = (uint16_t)len;
+                    const uint32_t scaled = (s.lqi / 8u) << 3;
+                    p->lqi = (uint8_t)(scaled >= 256u ? 255u : scaled);
+                    p->pdu_type = 0;
+                    p->flags = 0;
+                    p->aux = li;
+                    // FCS: CRC-16 over all but the last two bytes == those two bytes (LE)
+                    const uint32_t rx = s.b_prev | (s.b_last << 8);
+                    p->crc_ok = (uint8_t)(len >= 3u && s.c2 == rx);
+                }
+                n_pk++;
+            }
+            enter_search(s);
         }
     }
-    bool done = !active || avail < 8u;
-    const bool tap = active && g == soft_lane && soft_chips != nullptr;
-
-    // Tile t+1 is fetched into registers (one value per row) while tile t is consumed from LDS.
-    // Row = lane whose samples are loaded: its base and length come from v_readlane (SGPRs) and
-    // form a buffer descriptor, so reads past the lane's end return 0 without a branch.
-    float pre[64];
-    auto fetch_tile = [&](uint32_t r0) {
-        const uint32_t voff = (r0 + l) * 4u;
-#pragma unroll
-        for (uint32_t row = 0; row < 64u; row++) {
-            const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)row);
-            const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), (int)row);
-            const uint32_t av = (uint32_t)__builtin_amdgcn_readlane((int)(done ? 0u : avail), (int)row);
-            const float* rp = d + (((uint64_t)b_hi << 32) | b_lo);
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rp, 0, (int)(av * 4u), 0x00020000);
-            pre[row] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
-        }
-    };
-    fetch_tile(0u);
-    for (uint32_t tile = 0; ; tile++) {
-        if (__ballot(!done) == 0ull) break;
-        const uint32_t r0 = tile * 64u;
-        // ---- stage the prefetched tile: thread l holds sample r0+l of every row (lane)
-        {
-            const uint32_t tt = (r0 + l) & (kRingLen - 1);
-#pragma unroll
-            for (uint32_t row = 0; row < 64u; row++) ring[row * kRingStride + tt] = pre[row];
-        }
-        __builtin_amdgcn_wave_barrier();    // one wave per workgroup: LDS is program-ordered
-        fetch_tile(r0 + 64u);               // in flight while this tile is processed
-        if constexpr (RESUME) {
-            if (tile == 0 && active) {      // the 16 filtered samples before znext
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; k++) ring[l * kRingStride + 48u + k] = sv.zhist[k];
-            }
-        }
-        const uint32_t staged = r0 + 64u;
-        const uint32_t hi = staged < avail ? staged : avail;
-        if (!done) {
-            // ---- phase 1: a5 + a6 over this tile.  Hard chip decisions and the window advance of
-            //      every chip are packed into three 64-bit words (<= 64 chips per 64-sample tile):
-            //      chip c sits at bit 63-c, so a run of chips is one shift away from the sink's
-            //      shift-register order.
-            uint64_t cw = 0, d_lo = 0, d_hi = 0;
-            uint32_t nc = 0;
-            const uint32_t ii_start = ii;
-            float* row = &ring[l * kRingStride];
-            // a5: DC removal of the staged tile (sequential fp64 recurrence, 8 samples per step);
-            // a resumed lane's first tile is already filtered (its last 16 values were restored)
-            if (!(RESUME && tile == 0)) {
-                const uint32_t t0 = r0 & (kRingLen - 1);
-#pragma unroll 2
-                for (uint32_t q = 0; q < 64u; q += 8u) {
-                    float xv[8];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8u; k++) xv[k] = row[t0 + q + k];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8u; k++) {
-                        lp = alpha * (double)xv[k] + one_minus * lp;
-                        xv[k] = xv[k] - (float)lp;
-                        row[t0 + q + k] = xv[k];
-                    }
-                    if (t0 + q == 0u) {                 // mirror of entries 0..7
-#pragma unroll
-                        for (uint32_t k = 0; k < 8u; k++) row[kRingLen + k] = xv[k];
-                    }
-                    if (tap && soft_z) {
-#pragma unroll
-                        for (uint32_t k = 0; k < 8u; k++)
-                            if (r0 + q + k + origin < soft_cap) soft_z[r0 + q + k + origin] = xv[k];
-                    }
-                }
-                znext = staged;
-            }
-            // a6: Mueller & Mueller steps with the 8-tap MMSE interpolator
-            while (ii + 8u <= hi) {
-                const int imu = (int)rintf(mu * 128.0f);
-                const float4 t0 = *reinterpret_cast<const float4*>(&taps[imu * 8]);
-                const float4 t1 = *reinterpret_cast<const float4*>(&taps[imu * 8 + 4]);
-                const float* w = &row[ii & (kRingLen - 1)];        // 8 consecutive samples, no wrap
-                float acc = 0.0f;
-                acc = __builtin_fmaf(t0.x, w[7], acc);
-                acc = __builtin_fmaf(t0.y, w[6], acc);
-                acc = __builtin_fmaf(t0.z, w[5], acc);
-                acc = __builtin_fmaf(t0.w, w[4], acc);
-                acc = __builtin_fmaf(t1.x, w[3], acc);
-                acc = __builtin_fmaf(t1.y, w[2], acc);
-                acc = __builtin_fmaf(t1.z, w[1], acc);
-                acc = __builtin_fmaf(t1.w, w[0], acc);
-                const float o = acc;
-                if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o;
-                const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
-                last = o;
-                omega = omega + gain_omega * mm;
-                {
-                    const float x = omega - omega_mid;
-                    const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
-                    omega = omega_mid + c;
-                }
-                mu = mu + omega + gain_mu * mm;
-                const float fl = floorf(mu);
-                const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
-                ii += step;
-                mu = mu - fl;
-                const uint64_t pos_bit = 1ull << (63u - nc);
-                if (o > 0.0f) cw |= pos_bit;
-                if ((step - 1u) & 1u) d_lo |= pos_bit;
-                if ((step - 1u) & 2u) d_hi |= pos_bit;
-                nc++;
-            }
-
-            // ---- phase 2: a7 over the tile's chips
-            uint32_t c = 0, pos = ii_start;     // pos = window start of chip c (shifted coordinates)
-            while (c < nc) {
-                bool fin = false;
-                if (s.state == 0 && s.preamble_cnt == 0) {
-                    const uint32_t bit = (uint32_t)(cw >> (63u - c)) & 1u;
-                    const uint32_t step = 1u + ((uint32_t)(d_lo >> (63u - c)) & 1u) + 2u * ((uint32_t)(d_hi >> (63u - c)) & 1u);
-                    sink_search_chip(s, bit, pos + origin, th);
-                    pos += step;
-                    c++;
-                    if (s.preamble_cnt == 1 && s.trigger >= rel_core_end) { done = true; break; }  // next lane's
-                } else {
-                    // shift in the chips up to the next symbol boundary (or the end of the tile)
-                    const uint32_t need = 32u - (uint32_t)s.chip_cnt;
-                    const uint32_t take = need < nc - c ? need : nc - c;
-                    const uint64_t fld = (take == 64u) ? ~0ull : ~(~0ull >> take);     // top `take` bits
-                    const uint64_t bits = ((cw << c) & fld) >> (64u - take);
-                    s.shift = take >= 32u ? (uint32_t)bits : ((s.shift << take) | (uint32_t)bits);
-                    pos += take + (uint32_t)__popcll((d_lo << c) & fld) + 2u * (uint32_t)__popcll((d_hi << c) & fld);
-                    c += take;
-                    s.chip_cnt += (int)take;
-                    if (s.chip_cnt == 32) {
-                        uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
-                        fin = sink_symbol(s, th, pb);
-                    }
-                }
-                if (fin) {
-                    if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
-                        if (n_pk < K) {
-                            snout_pkt* p = &stage[(size_t)g * K + n_pk];
-                            const uint32_t len = (uint32_t)s.packetlen_cnt;
-                            for (uint32_t b = len; b < 136u; b++) p->bytes[b] = 0;
-                            p->sample_index = first_index + s0 + s.trigger;
-                            p->proto = SNOUT_PROTO_ZIGBEE;
-                            p->channel = slot_channel[slot];
-                            p->len = (uint16_t)len;
-                            const uint32_t scaled = (s.lqi / 8u) << 3;
-                            p->lqi = (uint8_t)(scaled >= 256u ? 255u : scaled);
-                            p->pdu_type = 0;
-                            p->flags = 0;
-                            p->aux = li;
-                            // FCS: CRC-16 over all but the last two bytes == those two bytes (LE)
-                            const uint32_t rx = s.b_prev | (s.b_last << 8);
-                            p->crc_ok = (uint8_t)(len >= 3u && s.c2 == rx);
-                        }
-                        n_pk++;
-                    }
-                    enter_search(s);
-                }
-                // the sequential receiver stops once it is idle past the end of its core
-                if (s.state == 0 && s.preamble_cnt == 0 && pos + origin >= rel_core_end) { done = true; break; }
-            }
-            n_chips += c;       // chips the sequential lane would have consumed so far
-            if (!done && !RESUME && pos + origin >= rel_core_end) {
-                // inside a frame at the end of the core: hand it to the second pass if this lane owns
-                // it, drop it otherwise (never reported, and the lane would stop right after it)
-                if (s.trigger >= rel_core_start && s.trigger < rel_core_end) {
-                    ZbLaneSave o2;
-                    o2.lp = lp; o2.mu = mu; o2.omega = omega; o2.last = last;
-                    o2.g = g; o2.ii = ii; o2.znext = znext; o2.n_pk = n_pk; o2.n_chips = n_chips;
-                    o2.s = s;
-#pragma unroll
-                    for (uint32_t k = 0; k < 16u; k++)
-                        o2.zhist[k] = row[((znext - 16u + k) & (kRingLen - 1))];
-                    saves[atomicAdd(n_saves, 1u)] = o2;
-                }
-                done = true;
-            }
-            if (hi >= avail && ii + 8u > avail) done = true;      // ran out of samples
-        }
-        __builtin_amdgcn_wave_barrier();    // one wave per workgroup: LDS is program-ordered
-    }
-    if (active) lane_cnt[g] = n_pk;
-    if (tap && soft_n) *soft_n = n_chips;
+    lane_cnt[g] = n_pk;
 }
 
 // Ordered compaction of per-lane records: lane g holds min(lane_cnt[g], K) records.
@@ -626,7 +856,8 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
 void ZbCtx::destroy()
 {
     d_atan.release(); d_mmse.release(); d_slot_channel.release();
-    d_d.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release(); d_saves.release();
+    d_dT.release(); d_TR.release(); d_lane_out.release(); d_cand.release(); d_lane_u32.release();
+    d_stream.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
     d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
 }
 
@@ -634,14 +865,23 @@ int ZbCtx::reserve(uint64_t n)
 {
     lanes_per_slot = cdiv(n, core);
     total_lanes = lanes_per_slot * n_slots;
-    d_stride = n + 64;
+    n_waves = cdiv(total_lanes, 64);
+    nt = (core + warmup) / 64u + 1u;
+    tiles_per_slot = cdiv(lanes_per_slot, kScanTile);
+    stream_words = n / 64u + 4u;                    // at most one chip per sample
     if (cdiv(total_lanes, 1024) > kMaxTiles) { set_last_error("too many lanes"); return SNOUT_ERANGE; }
-    if (int rc = d_d.ensure(d_stride * n_slots * 4u)) return rc;
+    if ((uint64_t)n_waves * nt > 0x7FFFFFFFull) { set_last_error("too many lane tiles"); return SNOUT_ERANGE; }
+    if (int rc = d_dT.ensure((uint64_t)n_waves * nt * 4096u * 4u)) return rc;
+    if (int rc = d_TR.ensure((uint64_t)n_waves * nt * 9u * 64u * 4u)) return rc;
+    if (int rc = d_lane_out.ensure((uint64_t)total_lanes * 32u)) return rc;
+    if (int rc = d_cand.ensure((uint64_t)total_lanes * 12u * 4u)) return rc;
+    // first_owned | owned | offs | tsum | slot_total
+    if (int rc = d_lane_u32.ensure(((uint64_t)total_lanes * 3u + (uint64_t)tiles_per_slot * n_slots + n_slots) * 4u)) return rc;
+    if (int rc = d_stream.ensure(stream_words * n_slots * 8u * 2u)) return rc;     // chips | match masks
     if (int rc = d_stage.ensure((uint64_t)total_lanes * pkts_per_lane * sizeof(snout_pkt))) return rc;
     if (int rc = d_lane_cnt.ensure(((uint64_t)total_lanes + 1024u) * 4u)) return rc;
     max_out = total_lanes * pkts_per_lane;
     if (int rc = d_soft.ensure(((uint64_t)kSoftCap * 2u + 16u) * 4u)) return rc;
-    if (int rc = d_saves.ensure((uint64_t)total_lanes * sizeof(ZbLaneSave))) return rc;
     nsb = (n + 63u) / 64u;
     if (int rc = d_S.ensure(nsb * n_slots * 8u)) return rc;
     if (int rc = d_Lblk.ensure((uint64_t)total_lanes * 8u)) return rc;
@@ -649,32 +889,41 @@ int ZbCtx::reserve(uint64_t n)
     return 0;
 }
 
-int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st, int soft_lane)
+// a5-a7 on the discriminator tiles: lanes -> stitched chip streams -> sinks -> per-lane records.
+int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st)
 {
-    float* sz = soft_lane >= 0 ? d_soft.as<float>() : nullptr;
-    float* sc = soft_lane >= 0 ? d_soft.as<float>() + kSoftCap : nullptr;
-    uint32_t* sn = soft_lane >= 0 ? (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap) : nullptr;
-    uint32_t* n_saves = (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap) + 4;
-    SNOUT_HIP(hipMemsetAsync(n_saves, 0, 4, st));
-    hipLaunchKernelGGL(zb_lanes<false>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
-                       d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
-                       d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
-                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), d_lp_in.as<double>(),
-                       d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
-                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
-    // second pass: the lanes that stopped inside a frame (grid covers the worst case; waves beyond
-    // the saved count exit at once)
-    hipLaunchKernelGGL(zb_lanes<true>, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), n,
-                       d_stride, lanes_per_slot, total_lanes, core, warmup, threshold,
-                       d_slot_channel.as<uint16_t>(), first_index, d_mmse.as<float>(),
-                       d_stage.as<snout_pkt>(), pkts_per_lane, d_lane_cnt.as<uint32_t>(), d_lp_in.as<double>(),
-                       d_saves.as<ZbLaneSave>(), n_saves, sz, sc,
-                       (uint32_t)(soft_lane >= 0 ? soft_lane : 0xFFFFFFFF), (uint32_t)kSoftCap, sn);
+    uint32_t* first_owned = d_lane_u32.as<uint32_t>();
+    uint32_t* owned = first_owned + total_lanes;
+    uint32_t* offs = owned + total_lanes;
+    uint32_t* tsum = offs + total_lanes;
+    uint32_t* slot_total = tsum + (uint64_t)tiles_per_slot * n_slots;
+    SNOUT_HIP(hipMemsetAsync(d_stream.p, 0, stream_words * n_slots * 8u, st));
+    hipLaunchKernelGGL(zb_mm<false>, dim3(n_waves), dim3(64), 0, st, d_dT.as<float>(), n, nt, lanes_per_slot,
+                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
+                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
+                       (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(zb_stitch, dim3(tiles_per_slot, n_slots), dim3(256), 0, st,
+                       d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(), lanes_per_slot, core, warmup,
+                       tiles_per_slot, first_owned, owned, tsum);
+    hipLaunchKernelGGL(zb_offsets, dim3(tiles_per_slot, n_slots), dim3(256), 0, st, owned, tsum,
+                       lanes_per_slot, tiles_per_slot, offs, slot_total);
+    hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
+                       lanes_per_slot, total_lanes, first_owned, offs,
+                       d_stream.as<unsigned long long>(), stream_words);
+    hipLaunchKernelGGL(zb_match, dim3(cdiv(stream_words, 256), n_slots), dim3(256), 0, st,
+                       d_stream.as<unsigned long long>(), stream_words, slot_total, threshold,
+                       d_stream.as<unsigned long long>() + stream_words * n_slots);
+    hipLaunchKernelGGL(zb_walk, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st,
+                       d_stream.as<unsigned long long>(), d_stream.as<unsigned long long>() + stream_words * n_slots,
+                       stream_words, offs, first_owned, slot_total,
+                       d_TR.as<uint32_t>(), nt, lanes_per_slot, total_lanes, core, warmup, threshold,
+                       d_slot_channel.as<uint16_t>(), first_index, d_stage.as<snout_pkt>(), pkts_per_lane,
+                       d_lane_cnt.as<uint32_t>());
     SNOUT_HIP(hipGetLastError());
     return 0;
 }
 
-// Test tap: soft intermediates of one lane of the LAST processed segment (d is still resident).
+// Test tap: soft intermediates of one lane of the LAST processed segment (the tiles are still resident).
 int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out)
 {
     *n_out = 0;
@@ -682,19 +931,33 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
         // `lane` selects the channel slot here
         if (lane >= n_slots) return SNOUT_EINVAL;
         const uint64_t m = n < cap ? n : cap;
-        SNOUT_HIP(hipMemcpy(out, d_d.as<float>() + (uint64_t)lane * d_stride, m * 4u, hipMemcpyDeviceToHost));
+        DevBuf tmp;
+        if (int rc = tmp.ensure((m ? m : 1) * 4u)) return rc;
+        if (m) {
+            hipLaunchKernelGGL(zb_gather_d, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, d_dT.as<float>(), n, lane,
+                               lanes_per_slot, core, warmup, nt, tmp.as<float>(), m);
+            SNOUT_HIP(hipMemcpy(out, tmp.p, m * 4u, hipMemcpyDeviceToHost));
+        }
+        tmp.release();
         *n_out = n;
         return n > cap ? SNOUT_EOVERFLOW : 0;
     }
     if (lane >= total_lanes) return SNOUT_EINVAL;
-    if (int rc = launch_lanes(n, 0, nullptr, (int)lane)) return rc;
+    float* sz = d_soft.as<float>();
+    float* sc = d_soft.as<float>() + kSoftCap;
+    uint32_t* sn = (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap);
+    // re-run the lanes with the tap on (rewrites identical tile records)
+    hipLaunchKernelGGL(zb_mm<true>, dim3(n_waves), dim3(64), 0, nullptr, d_dT.as<float>(), n, nt, lanes_per_slot,
+                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
+                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
+                       sz, sc, lane, (uint32_t)kSoftCap, sn);
     SNOUT_HIP(hipDeviceSynchronize());
     uint32_t nch = 0;
-    SNOUT_HIP(hipMemcpy(&nch, d_soft.as<float>() + 2 * kSoftCap, 4, hipMemcpyDeviceToHost));
+    SNOUT_HIP(hipMemcpy(&nch, sn, 4, hipMemcpyDeviceToHost));
     if (stage_id == SNOUT_STAGE_ZB_CHIPS) {
         const uint64_t have = nch < (uint32_t)kSoftCap ? nch : (uint32_t)kSoftCap;
         const uint64_t m = have < cap ? have : cap;
-        SNOUT_HIP(hipMemcpy(out, d_soft.as<float>() + kSoftCap, m * 4u, hipMemcpyDeviceToHost));
+        SNOUT_HIP(hipMemcpy(out, sc, m * 4u, hipMemcpyDeviceToHost));
         *n_out = have;
         return have > cap ? SNOUT_EOVERFLOW : 0;
     }
@@ -703,10 +966,10 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
         const uint64_t li = lane % lanes_per_slot;
         const uint64_t cs = li * (uint64_t)core, s0 = cs > warmup ? cs - warmup : 0;
         uint64_t have = n > s0 ? n - s0 : 0;
-        have = std::min<uint64_t>(have, (uint64_t)warmup + core);     // always filtered that far
+        have = std::min<uint64_t>(have, (cs - s0) + core);     // always filtered that far
         have = std::min<uint64_t>(have, kSoftCap);
         const uint64_t m = have < cap ? have : cap;
-        SNOUT_HIP(hipMemcpy(out, d_soft.as<float>(), m * 4u, hipMemcpyDeviceToHost));
+        SNOUT_HIP(hipMemcpy(out, sz, m * 4u, hipMemcpyDeviceToHost));
         *n_out = have;
         return have > cap ? SNOUT_EOVERFLOW : 0;
     }
@@ -723,15 +986,20 @@ int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t f
     uint32_t* sums = tot + 16;
     uint32_t* over = tot + 16 + kMaxTiles;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
-    const uint32_t gd = std::min<uint32_t>(cdiv(nsb * n_slots, 4), 256u * 16u);
-    hipLaunchKernelGGL(zb_discrim, dim3(gd), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
-                       n_slots, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(), d_stride,
-                       d_S.as<double>());
+    if (n < 9u) {           // no interpolator window fits: nothing to launch
+        SNOUT_HIP(hipMemsetAsync(tot, 0, 16, st));
+        if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
+        return 0;
+    }
+    hipLaunchKernelGGL(zb_discrim, dim3(n_waves * nt), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
+                       lanes_per_slot, total_lanes, core, warmup, nt, nsb, d_atan.as<float>(),
+                       d_iirw.as<double>(), d_dT.as<float>(), d_S.as<double>());
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
-    hipLaunchKernelGGL(zb_iir_scan, dim3(n_slots), dim3(64), 0, st, d_Lblk.as<double>(),
-                       lanes_per_slot, n_slots, dfirst, dcore, d_lp_in.as<double>());
-    if (int rc = launch_lanes(n, first_index, st, -1)) return rc;
+    hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
+                       lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
+                       d_lp_in.as<double>());
+    if (int rc = launch_lanes(n, first_index, st)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
     launch_tile_reduce(d_lane_cnt.as<uint32_t>(), nullptr, total_lanes, total_lanes, pkts_per_lane,
