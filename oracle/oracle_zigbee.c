@@ -300,8 +300,8 @@ static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_
  * started the recurrence from zero would see the uncorrected CFO offset for its first thousands of
  * samples.  The linear recurrence is therefore carried across lanes exactly as a blocked evaluation
  * of the same filter (all in double, fixed operation order, the GPU does the same):
- *   S_j   = sum over the 64 samples of sub-block j of  w[63-k] * d[64 j + k],  w[m] = alpha (1-alpha)^m,
- *           terms summed pairwise: v[i] += v[i+off] for off = 32,16,8,4,2,1   (zero-state response)
+ *   S_j   = (P0 + P1) + (P2 + P3),  P_p = sum in sequence, from 0, over k = 16p .. 16p+15 of
+ *           w[63-k] * d[64 j + k],  w[m] = alpha (1-alpha)^m                  (zero-state response)
  *   L_i   = fold over the sub-blocks of lane block i:  L = D64 * L + S_j
  *   lp_in[l] = fold over the lane blocks i = max(0, l - W) .. l-1, from 0:  lp = Dblk_i * lp + L_i
  * where lane block i = [s0_i, s0_{i+1}), s0_i = max(0, i core - warmup), D64 = (1-alpha)^64,
@@ -335,14 +335,16 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
     const uint64_t nsb = (n + 63) / 64;
     double* S = (double*)malloc((nsb ? nsb : 1) * sizeof(double));
     for (uint64_t j = 0; j < nsb; j++) {
-        double v[64];
-        for (int k = 0; k < 64; k++) {
-            const uint64_t t = 64 * j + (uint64_t)k;
-            v[k] = w[63 - k] * (double)(t < n ? d[t] : 0.0f);
+        double P[4];
+        for (int p = 0; p < 4; p++) {
+            double acc = 0.0;
+            for (int k = 16 * p; k < 16 * p + 16; k++) {
+                const uint64_t t = 64 * j + (uint64_t)k;
+                acc = acc + w[63 - k] * (double)(t < n ? d[t] : 0.0f);
+            }
+            P[p] = acc;
         }
-        for (int off = 32; off >= 1; off >>= 1)
-            for (int i = 0; i < off; i++) v[i] = v[i] + v[i + off];
-        S[j] = v[0];
+        S[j] = (P[0] + P[1]) + (P[2] + P[3]);
     }
     double* lp_in = (double*)malloc((n_lanes ? n_lanes : 1) * sizeof(double));
     const double dcore = pow_rep(d64, core / 64u);

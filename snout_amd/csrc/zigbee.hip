@@ -38,28 +38,21 @@ static const float kMmseTapsHost[129][8] = {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* __restrict__ tab)
 {
+    // Straight-line form of the oracle's branches (same operations on the taken path, selected).
     const float ya = fabsf(y), xa = fabsf(x);
-    if (!(ya > 0.0f || xa > 0.0f)) return 0.0f;
-    const float z = ya < xa ? ya / xa : xa / ya;
-    float base;
-    if (z < 0.003921569f) {
-        base = z;
-    } else {
-        float a = z * 255.0f;
-        const int k = ((int)a) & 0xff;
-        a -= (float)k;
-        const float t0 = tab[k];
-        base = t0 + (tab[k + 1] - t0) * a;
-    }
-    float ang;
-    if (xa > ya) {
-        if (x >= 0.0f) ang = y >= 0.0f ? base : -base;
-        else ang = y >= 0.0f ? 3.14159265358979323846f - base : base - 3.14159265358979323846f;
-    } else {
-        if (y >= 0.0f) ang = x >= 0.0f ? 1.57079632679489661923f - base : 1.57079632679489661923f + base;
-        else ang = x >= 0.0f ? -1.57079632679489661923f + base : -1.57079632679489661923f - base;
-    }
-    return ang;
+    const bool lt = ya < xa;
+    const float z = (lt ? ya : xa) / (lt ? xa : ya);         // 0/0 -> NaN, replaced below
+    const float a = z * 255.0f;
+    const int k = ((int)a) & 0xff;
+    const float t0 = tab[k];
+    const float interp = t0 + (tab[k + 1] - t0) * (a - (float)k);
+    const float base = z < 0.003921569f ? z : interp;
+    const float PI = 3.14159265358979323846f, H = 1.57079632679489661923f;
+    const bool xp = x >= 0.0f, yp = y >= 0.0f;
+    const float q_lt = xp ? (yp ? base : -base) : (yp ? PI - base : base - PI);
+    const float q_ge = yp ? (xp ? H - base : H + base) : (xp ? -H + base : -H - base);
+    const float ang = lt ? q_lt : q_ge;
+    return (ya > 0.0f || xa > 0.0f) ? ang : 0.0f;
 }
 
 constexpr uint32_t kTrFields = 9;  // tile record: cw lo/hi, d_lo lo/hi, d_hi lo/hi, nc, cstart, ii_start
@@ -75,18 +68,17 @@ __device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t
     return (((uint64_t)w * nt + t) * kTrFields + field) * 64u + row;
 }
 
-// One block per (wave of 64 lanes, 64-sample tile): wave v of the block computes rows 16v..16v+15
-// (row = lane, 64 consecutive samples each, coalesced 512-B reads), the block transposes through
-// LDS and writes the tile as 64 lines of 64 lanes (see dt_index).  The warm-up samples of a lane
-// are the last core samples of the previous one, so they are computed twice (1 + warmup/core reads
-// per sample).  For the rows that lie in their lane's core the wave also emits S_j, the zero-state
-// response of the single-pole IIR to the 64 samples (double, fixed pairwise order), from which
-// zb_iir_fold / zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the oracle).
+// One block per (wave of 64 lanes, 64-sample tile of their cores): wave v of the block computes rows
+// 16v..16v+15 (row = lane, 64 consecutive samples each, coalesced 512-B reads), the block
+// transposes through LDS and writes the tile as 64 lines of 64 lanes (see dt_index).  Only core
+// tiles are stored: a lane's warm-up samples are the last core tiles of the lane before it and
+// zb_mm reads them from there.  The block also emits S_j, the zero-state response of the
+// single-pole IIR to each row's 64 samples (double, fixed order), from which zb_iir_fold /
+// zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the oracle).
 __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq, uint64_t n,
                                                   uint64_t iq_stride, uint32_t lanes_per_slot,
-                                                  uint32_t total_lanes, uint32_t core, uint32_t warmup,
-                                                  uint32_t nt, uint64_t nsb,
-                                                  const float* __restrict__ atan_tab,
+                                                  uint32_t total_lanes, uint32_t core, uint32_t ntc,
+                                                  uint64_t nsb, const float* __restrict__ atan_tab,
                                                   const double* __restrict__ iir_w,
                                                   float* __restrict__ dT, double* __restrict__ S)
 {
@@ -96,17 +88,15 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
     for (uint32_t i = threadIdx.x; i < 257; i += 256) tab[i] = atan_tab[i];
     if (threadIdx.x < 64) wts[threadIdx.x] = iir_w[threadIdx.x];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, v = threadIdx.x >> 6;
-    const uint32_t w = blockIdx.x / nt, t = blockIdx.x % nt;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: row math on the SALU
+    const uint32_t w = blockIdx.x / ntc, t = blockIdx.x % ntc;
     for (uint32_t r = v * 16u; r < v * 16u + 16u; r++) {
         const uint32_t g = w * 64u + r;
         float ang = 0.0f;
         if (g < total_lanes) {
             const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
-            const uint64_t cs = (uint64_t)li * core;
-            const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
-            const uint64_t a0 = s0 + 64ull * t;             // first sample of the row
-            const uint64_t ta = a0 + lane;
+            const uint64_t ta = (uint64_t)li * core + 64ull * t + lane;
             const float2* x = iq + (uint64_t)slot * iq_stride;
             if (ta < n) {
                 const float2 a = x[ta];
@@ -116,18 +106,27 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
                 ang = fast_atan2f_tab(im, re, tab);
                 if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
             }
-            // sub-block sums only where the row is in the lane's core (every sub-block exactly once)
-            if (a0 >= cs && a0 < cs + core && (a0 >> 6) < nsb) {
-                double sv = wts[63u - lane] * (double)ang;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) sv = sv + __shfl_down(sv, off);
-                if (lane == 0) S[(uint64_t)slot * nsb + (a0 >> 6)] = sv;
-            }
         }
         tile[r * 65u + lane] = ang;
     }
     __syncthreads();
-    float* out = dT + ((uint64_t)w * nt + t) * 4096u;
+    // S_j of the wave's 16 rows (oracle order): four threads per row sum 16 terms each in sequence,
+    // S = (P0 + P1) + (P2 + P3)
+    {
+        const uint32_t r = v * 16u + (lane & 15u), part = lane >> 4;
+        double acc = 0.0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++)
+            acc = acc + wts[63u - (16u * part + k)] * (double)tile[r * 65u + 16u * part + k];
+        acc = acc + __shfl_down(acc, 16);
+        acc = acc + __shfl_down(acc, 32);
+        const uint32_t g = w * 64u + r;
+        if (lane < 16u && g < total_lanes) {
+            const uint64_t j = ((uint64_t)(g % lanes_per_slot) * core + 64ull * t) >> 6;
+            if (j < nsb) S[(uint64_t)(g / lanes_per_slot) * nsb + j] = acc;
+        }
+    }
+    float* out = dT + ((uint64_t)w * ntc + t) * 4096u;
 #pragma unroll
     for (uint32_t k = 0; k < 16u; k++) {
         const uint32_t idx = k * 256u + threadIdx.x;        // = col * 64 + row
@@ -137,17 +136,15 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
 
 // Test tap: channel-ordered discriminator output of one slot, gathered from the core tiles.
 __global__ __launch_bounds__(256) void zb_gather_d(const float* __restrict__ dT, uint64_t n, uint32_t slot,
-                                                   uint32_t lanes_per_slot, uint32_t core, uint32_t warmup,
-                                                   uint32_t nt, float* __restrict__ out, uint64_t cap)
+                                                   uint32_t lanes_per_slot, uint32_t core, uint32_t ntc,
+                                                   float* __restrict__ out, uint64_t cap)
 {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= n || t >= cap) return;
     const uint32_t li = (uint32_t)(t / core);
-    const uint64_t cs = (uint64_t)li * core;
-    const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
-    const uint32_t rel = (uint32_t)(t - s0);
+    const uint32_t rel = (uint32_t)(t - (uint64_t)li * core);
     const uint32_t g = slot * lanes_per_slot + li;
-    out[t] = dT[dt_index(g >> 6, nt, rel >> 6, rel & 63u, g & 63u)];
+    out[t] = dT[dt_index(g >> 6, ntc, rel >> 6, rel & 63u, g & 63u)];
 }
 
 // Lane block i = [s0_i, s0_{i+1}): fold its sub-block sums, L = D64 L + S_j (one thread per lane).
@@ -242,9 +239,29 @@ __global__ __launch_bounds__(64) void zb_mm(
 #pragma unroll
     for (int k = 0; k < 8; k++) zl[k] = 0.0f;
 
+    // Where tile t of this lane lives: warm-up tiles are the last core tiles of the lane before,
+    // the tail tile is the first core tile of the lane after (only core tiles are stored).
+    const uint32_t ntc = core >> 6;
+    const uint32_t g_next = (active && li + 1u < lanes_per_slot) ? g + 1u : g;     // tail unused if no next lane
+    auto tile_ptr = [&](uint32_t t) -> const float* {
+        uint32_t sg = g, tc = 0;
+        if (li == 0u || !active) {
+            if (t < ntc) tc = t; else if (t == ntc) sg = g_next;
+        } else if (t < tb) {
+            sg = g - 1u; tc = ntc - tb + t;
+        } else if (t < tb + ntc) {
+            tc = t - tb;
+        } else {
+            sg = g_next;
+        }
+        return dT + dt_index(sg >> 6, ntc, tc, 0u, sg & 63u);
+    };
     float pre[64];
+    {
+        const float* tp = tile_ptr(0u);
 #pragma unroll
-    for (uint32_t col = 0; col < 64u; col++) pre[col] = dT[dt_index(w, nt, 0u, col, l)];
+        for (uint32_t col = 0; col < 64u; col++) pre[col] = tp[col * 64u];
+    }
 
     for (uint32_t tile = 0; tile < nt; tile++) {
         const uint32_t r0 = tile * 64u;
@@ -269,8 +286,9 @@ __global__ __launch_bounds__(64) void zb_mm(
         }
         // ---- next tile's samples: in flight during the M&M steps
         if (tile + 1u < nt) {
+            const float* tp = tile_ptr(tile + 1u);
 #pragma unroll
-            for (uint32_t col = 0; col < 64u; col++) pre[col] = dT[dt_index(w, nt, tile + 1u, col, l)];
+            for (uint32_t col = 0; col < 64u; col++) pre[col] = tp[col * 64u];
         }
         // ---- a6: the M&M steps whose window starts in this tile
         const uint32_t staged = r0 + nz;
@@ -449,36 +467,29 @@ __global__ __launch_bounds__(256) void zb_offsets(const uint32_t* __restrict__ o
 }
 
 // Owned chips of every lane -> the channel's chip stream (chip q at bit 63 - q % 64 of word q / 64).
-// Thread = lane; the tile records of 64 consecutive lanes are read as coalesced lines.
+// One thread per (lane, tile record); the records of 64 consecutive lanes are coalesced lines.
 __global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ TR, uint32_t nt,
                                                   uint32_t lanes_per_slot, uint32_t total_lanes,
                                                   const uint32_t* __restrict__ first_owned,
                                                   const uint32_t* __restrict__ offs,
                                                   unsigned long long* __restrict__ stream, uint64_t stream_words)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x, t = blockIdx.y;
     if (g >= total_lanes) return;
     const uint32_t w = g >> 6, row = g & 63u;
-    const uint32_t slot = g / lanes_per_slot;
-    const uint32_t f = first_owned[g], o = offs[g];
-    unsigned long long* sw = stream + (uint64_t)slot * stream_words;
-    uint32_t c = 0;
-    for (uint32_t t = 0; t < nt; t++) {
-        const uint32_t nc = TR[tr_index(w, nt, t, 6, row)];
-        if (nc == 0u) continue;
-        const uint32_t lo = f > c ? f : c;
-        if (lo < c + nc) {
-            const uint64_t cw = (uint64_t)TR[tr_index(w, nt, t, 0, row)] |
-                                ((uint64_t)TR[tr_index(w, nt, t, 1, row)] << 32);
-            const uint32_t skip = lo - c, cnt = nc - skip;
-            const uint64_t bits = (cw << skip) & (~0ull << (64u - cnt));
-            const uint32_t q = o + (lo - f);
-            const uint32_t sh = q & 63u;
-            atomicOr(&sw[q >> 6], bits >> sh);
-            if (sh + cnt > 64u) atomicOr(&sw[(q >> 6) + 1u], bits << (64u - sh));
-        }
-        c += nc;
-    }
+    const uint32_t nc = TR[tr_index(w, nt, t, 6, row)];
+    const uint32_t c = TR[tr_index(w, nt, t, 7, row)];       // lane chip index of the tile's first chip
+    const uint32_t f = first_owned[g];
+    const uint32_t lo = f > c ? f : c;
+    if (lo >= c + nc) return;                               // empty tile, or all its chips are warm-up
+    const uint64_t cw = (uint64_t)TR[tr_index(w, nt, t, 0, row)] | ((uint64_t)TR[tr_index(w, nt, t, 1, row)] << 32);
+    const uint32_t skip = lo - c, cnt = nc - skip;
+    const uint64_t bits = (cw << skip) & (~0ull << (64u - cnt));
+    const uint32_t q = offs[g] + (lo - f);
+    const uint32_t sh = q & 63u;
+    unsigned long long* sw = stream + (uint64_t)(g / lanes_per_slot) * stream_words;
+    atomicOr(&sw[q >> 6], bits >> sh);
+    if (sh + cnt > 64u) atomicOr(&sw[(q >> 6) + 1u], bits << (64u - sh));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -506,30 +517,35 @@ __device__ __forceinline__ uint32_t chip_dist(uint32_t shift, uint32_t word)
 
 __device__ __forceinline__ int decode_chips(SinkState& s, uint32_t th)
 {
-    // words 8..15 are the 30-bit complements of words 0..7 (under the mask): dist = 30 - dist
-    uint32_t dlo[8];
+    // The sink takes the first of the 16 words with the smallest distance.  Words 8..15 are the
+    // 30-bit complements of words 0..7 (under the mask), dist = 30 - dist, so: first minimum of
+    // d[0..7] (key d*8 + i, smallest wins), first maximum of d[0..7] (key d*8 + 7-i, largest wins),
+    // and the lower half wins a tie between the two.
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
-    for (int i = 0; i < 8; i++) dlo[i] = chip_dist(s.shift, kChipMap[i]);
-    int best = 0xFF;
-    uint32_t min_t = 33;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t t = i < 8 ? dlo[i] : 30u - dlo[i - 8];
-        if (t < min_t) { best = i; min_t = t; }
+    for (uint32_t i = 0; i < 8u; i++) {
+        const uint32_t d = chip_dist(s.shift, kChipMap[i]);
+        const uint32_t a = d * 8u + i, b = d * 8u + (7u - i);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
     }
+    const uint32_t d_lo = kmin >> 3, d_hi = 30u - (kmax >> 3);
+    const bool low = d_lo <= d_hi;
+    const uint32_t min_t = low ? d_lo : d_hi;
+    const int best = (int)(low ? (kmin & 7u) : 8u + (7u - (kmax & 7u)));
     if (min_t < th) {
         if (s.lqi_cnt < 8) { s.lqi += 32 - min_t; s.lqi_cnt++; }
-        return best & 0xF;
+        return best;
     }
     return 0xFF;
 }
 
+// One byte of the reflected CCITT CRC (poly 0x8408), closed form of the eight shift steps.
 __device__ __forceinline__ uint32_t crc16_step(uint32_t c, uint32_t byte)
 {
-    c ^= byte;
-#pragma unroll
-    for (int k = 0; k < 8; k++) c = (c & 1u) ? ((c >> 1) ^ 0x8408u) : (c >> 1);
-    return c;
+    uint32_t x = (c ^ byte) & 0xFFu;
+    x ^= (x << 4) & 0xFFu;
+    return ((c >> 8) ^ (x << 8) ^ (x << 3) ^ (x >> 4)) & 0xFFFFu;
 }
 
 // Called at a symbol boundary (32 chips after the previous one; s.shift holds the symbol's chips).
@@ -871,7 +887,7 @@ int ZbCtx::reserve(uint64_t n)
     stream_words = n / 64u + 4u;                    // at most one chip per sample
     if (cdiv(total_lanes, 1024) > kMaxTiles) { set_last_error("too many lanes"); return SNOUT_ERANGE; }
     if ((uint64_t)n_waves * nt > 0x7FFFFFFFull) { set_last_error("too many lane tiles"); return SNOUT_ERANGE; }
-    if (int rc = d_dT.ensure((uint64_t)n_waves * nt * 4096u * 4u)) return rc;
+    if (int rc = d_dT.ensure((uint64_t)n_waves * (core / 64u) * 4096u * 4u)) return rc;
     if (int rc = d_TR.ensure((uint64_t)n_waves * nt * 9u * 64u * 4u)) return rc;
     if (int rc = d_lane_out.ensure((uint64_t)total_lanes * 32u)) return rc;
     if (int rc = d_cand.ensure((uint64_t)total_lanes * 12u * 4u)) return rc;
@@ -907,7 +923,7 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st)
                        tiles_per_slot, first_owned, owned, tsum);
     hipLaunchKernelGGL(zb_offsets, dim3(tiles_per_slot, n_slots), dim3(256), 0, st, owned, tsum,
                        lanes_per_slot, tiles_per_slot, offs, slot_total);
-    hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
+    hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256), nt), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
                        lanes_per_slot, total_lanes, first_owned, offs,
                        d_stream.as<unsigned long long>(), stream_words);
     hipLaunchKernelGGL(zb_match, dim3(cdiv(stream_words, 256), n_slots), dim3(256), 0, st,
@@ -935,7 +951,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
         if (int rc = tmp.ensure((m ? m : 1) * 4u)) return rc;
         if (m) {
             hipLaunchKernelGGL(zb_gather_d, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, d_dT.as<float>(), n, lane,
-                               lanes_per_slot, core, warmup, nt, tmp.as<float>(), m);
+                               lanes_per_slot, core, core / 64u, tmp.as<float>(), m);
             SNOUT_HIP(hipMemcpy(out, tmp.p, m * 4u, hipMemcpyDeviceToHost));
         }
         tmp.release();
@@ -991,8 +1007,8 @@ int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t f
         if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         return 0;
     }
-    hipLaunchKernelGGL(zb_discrim, dim3(n_waves * nt), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
-                       lanes_per_slot, total_lanes, core, warmup, nt, nsb, d_atan.as<float>(),
+    hipLaunchKernelGGL(zb_discrim, dim3(n_waves * (core / 64u)), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
+                       lanes_per_slot, total_lanes, core, core / 64u, nsb, d_atan.as<float>(),
                        d_iirw.as<double>(), d_dT.as<float>(), d_S.as<double>());
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
