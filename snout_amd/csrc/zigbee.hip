@@ -182,8 +182,9 @@ __global__ __launch_bounds__(256) void zb_iir_scan(const double* __restrict__ Lb
 // ---------------------------------------------------------------------------------------------
 // a5-a6: lanes (IIR + Mueller & Mueller), chips out.
 // ---------------------------------------------------------------------------------------------
-constexpr int kZRow = 73;          // per-lane z buffer: 8 samples of history + one 64-sample tile, odd stride
-constexpr int kTapStride = 131;    // tap-major MMSE table in LDS: tapsT[k * 131 + imu]
+constexpr int kZRow = 41;          // per-lane z buffer: 8 samples of history + half a 64-sample tile, odd stride
+// MMSE table in LDS as two float4 arrays (taps 0-3, taps 4-7 of every row): one ds_read_b128 each,
+// 16-B slot = row mod 16, so the 16 lanes of a read group spread over all slots
 constexpr uint32_t kMaxCand = 12;
 constexpr uint32_t kSinkWarmChips = 1024;   // sink warm-up on the stitched stream (ORACLE_ZB_SINK_WARM)
 
@@ -212,9 +213,12 @@ __global__ __launch_bounds__(64) void zb_mm(
     uint32_t* __restrict__ soft_n)
 {
     __shared__ float zb[64 * kZRow];
-    __shared__ float tapsT[8 * kTapStride];
+    __shared__ float4 tapsA[129], tapsB[129];
     const uint32_t l = threadIdx.x, w = blockIdx.x;
-    for (uint32_t i = l; i < 129u * 8u; i += 64u) tapsT[(i & 7u) * kTapStride + (i >> 3)] = mmse[i];
+    for (uint32_t i = l; i < 129u; i += 64u) {
+        tapsA[i] = make_float4(mmse[i * 8u + 0u], mmse[i * 8u + 1u], mmse[i * 8u + 2u], mmse[i * 8u + 3u]);
+        tapsB[i] = make_float4(mmse[i * 8u + 4u], mmse[i * 8u + 5u], mmse[i * 8u + 6u], mmse[i * 8u + 7u]);
+    }
     const uint32_t g = w * 64u + l;
     const bool active = g < total_lanes;
     const uint32_t li = active ? g % lanes_per_slot : 0u;
@@ -265,77 +269,84 @@ __global__ __launch_bounds__(64) void zb_mm(
 
     for (uint32_t tile = 0; tile < nt; tile++) {
         const uint32_t r0 = tile * 64u;
-        // ---- a5: DC removal of this tile (sequential fp64 recurrence); the last tile only feeds the
-        //      windows that start before the core end, 8 samples are enough
+        // The tile is consumed in two halves of 32 samples (the LDS row holds 8 + 32 samples, which
+        // lets ten waves share a CU): a5, DC removal (sequential fp64 recurrence), then a6, the M&M
+        // steps whose window ends inside the half.  The last tile only feeds the windows that start
+        // before the core end: 8 samples are enough.
         const uint32_t nz = (tile + 1u == nt) ? 8u : 64u;
-#pragma unroll
-        for (int k = 0; k < 8; k++) zrow[k] = zl[k];
-#pragma unroll
-        for (uint32_t q = 0; q < 64u; q += 8u) {
-            if (q < nz) {
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) {
-                    const float x = pre[q + k];
-                    lp = alpha * (double)x + one_minus * lp;
-                    const float z = x - (float)lp;
-                    zrow[8u + q + k] = z;
-                    zl[k] = z;
-                    if constexpr (TAP) { if (tap && soft_z && r0 + q + k < soft_cap) soft_z[r0 + q + k] = z; }
-                }
-            }
-        }
-        // ---- next tile's samples: in flight during the M&M steps
-        if (tile + 1u < nt) {
-            const float* tp = tile_ptr(tile + 1u);
-#pragma unroll
-            for (uint32_t col = 0; col < 64u; col++) pre[col] = tp[col * 64u];
-        }
-        // ---- a6: the M&M steps whose window starts in this tile
-        const uint32_t staged = r0 + nz;
-        const uint32_t hi = staged < avail ? staged : avail;
         const uint32_t cstart = n_chips, ii_start = ii;
         uint64_t d_lo = 0, d_hi = 0;
         uint32_t nc = 0;
         const bool cand_tile = tile == tb && li > 0u;
-        while (ii < rce && ii + 8u <= hi) {
-            const int imu = (int)rintf(mu * 128.0f);
-            const float* tp = &tapsT[imu];
-            const float* wv = &zrow[ii + 8u - r0];                // 8 consecutive samples
-            float acc = 0.0f;
-            acc = __builtin_fmaf(tp[0 * kTapStride], wv[7], acc);
-            acc = __builtin_fmaf(tp[1 * kTapStride], wv[6], acc);
-            acc = __builtin_fmaf(tp[2 * kTapStride], wv[5], acc);
-            acc = __builtin_fmaf(tp[3 * kTapStride], wv[4], acc);
-            acc = __builtin_fmaf(tp[4 * kTapStride], wv[3], acc);
-            acc = __builtin_fmaf(tp[5 * kTapStride], wv[2], acc);
-            acc = __builtin_fmaf(tp[6 * kTapStride], wv[1], acc);
-            acc = __builtin_fmaf(tp[7 * kTapStride], wv[0], acc);
-            const float o = acc;
-            if constexpr (TAP) { if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o; }
-            hist = (hist << 1) | (o > 0.0f ? 1ull : 0ull);
-            t_last = ii * 128u + (uint32_t)imu;
-            if (cand_tile && ii + 3u - rcs <= 8u && cand_n < kMaxCand) {
-                if (cand_n == 0u) c0 = n_chips + nc;
-                cand_keys[(size_t)g * kMaxCand + cand_n] = t_last;
-                cand_n++;
-                hist_cand = hist;
+#pragma unroll
+        for (uint32_t hb = 0; hb < 64u; hb += 32u) {
+            if (hb < nz) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) zrow[k] = zl[k];
+#pragma unroll
+                for (uint32_t q = 0; q < 32u; q += 8u) {
+                    if (hb + q < nz) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++) {
+                            const float x = pre[hb + q + k];
+                            lp = alpha * (double)x + one_minus * lp;
+                            const float z = x - (float)lp;
+                            zrow[8u + q + k] = z;
+                            zl[k] = z;
+                            if constexpr (TAP) { if (tap && soft_z && r0 + hb + q + k < soft_cap) soft_z[r0 + hb + q + k] = z; }
+                        }
+                    }
+                }
             }
-            const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
-            last = o;
-            omega = omega + gain_omega * mm;
-            {
-                const float x = omega - omega_mid;
-                const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
-                omega = omega_mid + c;
+            // next tile's samples: in flight during the second half's M&M steps
+            if (hb == 32u && tile + 1u < nt) {
+                const float* tp = tile_ptr(tile + 1u);
+#pragma unroll
+                for (uint32_t col = 0; col < 64u; col++) pre[col] = tp[col * 64u];
             }
-            mu = mu + omega + gain_mu * mm;
-            const float fl = floorf(mu);
-            const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
-            ii += step;
-            mu = mu - fl;
-            d_lo = (d_lo << 1) | ((step - 1u) & 1u);
-            d_hi = (d_hi << 1) | (((step - 1u) >> 1) & 1u);
-            nc++;
+            const uint32_t staged = r0 + (nz < hb + 32u ? nz : hb + 32u);
+            const uint32_t hi = staged < avail ? staged : avail;
+            const uint32_t zorg = r0 + hb - 8u;                      // sample held by zrow[0] (mod 2^32)
+            while (ii < rce && ii + 8u <= hi) {
+                const int imu = (int)rintf(mu * 128.0f);
+                const float4 ta = tapsA[imu], tb4 = tapsB[imu];
+                const float* wv = &zrow[ii - zorg];                   // 8 consecutive samples
+                float acc = 0.0f;
+                acc = __builtin_fmaf(ta.x, wv[7], acc);
+                acc = __builtin_fmaf(ta.y, wv[6], acc);
+                acc = __builtin_fmaf(ta.z, wv[5], acc);
+                acc = __builtin_fmaf(ta.w, wv[4], acc);
+                acc = __builtin_fmaf(tb4.x, wv[3], acc);
+                acc = __builtin_fmaf(tb4.y, wv[2], acc);
+                acc = __builtin_fmaf(tb4.z, wv[1], acc);
+                acc = __builtin_fmaf(tb4.w, wv[0], acc);
+                const float o = acc;
+                if constexpr (TAP) { if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o; }
+                hist = (hist << 1) | (o > 0.0f ? 1ull : 0ull);
+                t_last = ii * 128u + (uint32_t)imu;
+                if (cand_tile && ii + 3u - rcs <= 8u && cand_n < kMaxCand) {
+                    if (cand_n == 0u) c0 = n_chips + nc;
+                    cand_keys[(size_t)g * kMaxCand + cand_n] = t_last;
+                    cand_n++;
+                    hist_cand = hist;
+                }
+                const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+                last = o;
+                omega = omega + gain_omega * mm;
+                {
+                    const float x = omega - omega_mid;
+                    const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+                    omega = omega_mid + c;
+                }
+                mu = mu + omega + gain_mu * mm;
+                const float fl = floorf(mu);
+                const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
+                ii += step;
+                mu = mu - fl;
+                d_lo = (d_lo << 1) | ((step - 1u) & 1u);
+                d_hi = (d_hi << 1) | (((step - 1u) >> 1) & 1u);
+                nc++;
+            }
         }
         n_chips += nc;
         // ---- tile record: chip c of the tile at bit 63 - c
@@ -467,29 +478,48 @@ __global__ __launch_bounds__(256) void zb_offsets(const uint32_t* __restrict__ o
 }
 
 // Owned chips of every lane -> the channel's chip stream (chip q at bit 63 - q % 64 of word q / 64).
-// One thread per (lane, tile record); the records of 64 consecutive lanes are coalesced lines.
+// Thread = lane: it appends the owned part of its tile records to a 64-bit accumulator and stores
+// every completed word; only the two words it may share with its neighbours (the first if it
+// starts inside a word, and the last) are merged with atomicOr into the zeroed stream.  The
+// records of 64 consecutive lanes are coalesced lines.
 __global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ TR, uint32_t nt,
                                                   uint32_t lanes_per_slot, uint32_t total_lanes,
+                                                  uint32_t first_tile,
                                                   const uint32_t* __restrict__ first_owned,
                                                   const uint32_t* __restrict__ offs,
                                                   unsigned long long* __restrict__ stream, uint64_t stream_words)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x, t = blockIdx.y;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= total_lanes) return;
     const uint32_t w = g >> 6, row = g & 63u;
-    const uint32_t nc = TR[tr_index(w, nt, t, 6, row)];
-    const uint32_t c = TR[tr_index(w, nt, t, 7, row)];       // lane chip index of the tile's first chip
-    const uint32_t f = first_owned[g];
-    const uint32_t lo = f > c ? f : c;
-    if (lo >= c + nc) return;                               // empty tile, or all its chips are warm-up
-    const uint64_t cw = (uint64_t)TR[tr_index(w, nt, t, 0, row)] | ((uint64_t)TR[tr_index(w, nt, t, 1, row)] << 32);
-    const uint32_t skip = lo - c, cnt = nc - skip;
-    const uint64_t bits = (cw << skip) & (~0ull << (64u - cnt));
-    const uint32_t q = offs[g] + (lo - f);
-    const uint32_t sh = q & 63u;
+    const uint32_t f = first_owned[g], o = offs[g];
     unsigned long long* sw = stream + (uint64_t)(g / lanes_per_slot) * stream_words;
-    atomicOr(&sw[q >> 6], bits >> sh);
-    if (sh + cnt > 64u) atomicOr(&sw[(q >> 6) + 1u], bits << (64u - sh));
+    uint32_t wi = o >> 6, fill = o & 63u;
+    bool shared = fill != 0u;                   // the word being filled started before this lane
+    uint64_t acc = 0;
+    // chips before the candidate tile are never owned (a lane without predecessor owns from chip 0)
+    const uint32_t t0 = (g % lanes_per_slot) ? first_tile : 0u;
+#pragma unroll 4
+    for (uint32_t t = t0; t < nt; t++) {
+        const uint32_t nc = TR[tr_index(w, nt, t, 6, row)];
+        const uint32_t c = TR[tr_index(w, nt, t, 7, row)];   // lane chip index of the tile's first chip
+        const uint64_t cw = (uint64_t)TR[tr_index(w, nt, t, 0, row)] | ((uint64_t)TR[tr_index(w, nt, t, 1, row)] << 32);
+        const uint32_t lo = f > c ? f : c;
+        if (lo >= c + nc) continue;                         // empty tile, or all its chips are warm-up
+        const uint32_t skip = lo - c, cnt = nc - skip;
+        const uint64_t bits = (cw << skip) & (~0ull << (64u - cnt));
+        acc |= bits >> fill;
+        if (fill + cnt >= 64u) {
+            if (shared) atomicOr(&sw[wi], acc); else sw[wi] = acc;
+            shared = false;
+            wi++;
+            acc = fill ? bits << (64u - fill) : 0ull;
+            fill = fill + cnt - 64u;
+        } else {
+            fill += cnt;
+        }
+    }
+    if (fill != 0u && acc != 0ull) atomicOr(&sw[wi], acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -923,8 +953,8 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st)
                        tiles_per_slot, first_owned, owned, tsum);
     hipLaunchKernelGGL(zb_offsets, dim3(tiles_per_slot, n_slots), dim3(256), 0, st, owned, tsum,
                        lanes_per_slot, tiles_per_slot, offs, slot_total);
-    hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256), nt), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
-                       lanes_per_slot, total_lanes, first_owned, offs,
+    hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
+                       lanes_per_slot, total_lanes, warmup >= 64u ? (warmup >> 6) - 1u : 0u, first_owned, offs,
                        d_stream.as<unsigned long long>(), stream_words);
     hipLaunchKernelGGL(zb_match, dim3(cdiv(stream_words, 256), n_slots), dim3(256), 0, st,
                        d_stream.as<unsigned long long>(), stream_words, slot_total, threshold,
