@@ -91,23 +91,42 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: row math on the SALU
     const uint32_t w = blockIdx.x / ntc, t = blockIdx.x % ntc;
-    for (uint32_t r = v * 16u; r < v * 16u + 16u; r++) {
-        const uint32_t g = w * 64u + r;
-        float ang = 0.0f;
-        if (g < total_lanes) {
-            const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
-            const uint64_t ta = (uint64_t)li * core + 64ull * t + lane;
-            const float2* x = iq + (uint64_t)slot * iq_stride;
-            if (ta < n) {
-                const float2 a = x[ta];
-                const float2 p = ta ? x[ta - 1] : make_float2(0.0f, 0.0f);
-                const float re = a.x * p.x + a.y * p.y;      // contraction is off: products round first
-                const float im = a.y * p.x - a.x * p.y;
-                ang = fast_atan2f_tab(im, re, tab);
-                if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;      // non-finite input: defined as 0 (as the oracle)
-            }
+    // (slot, lane-in-slot) of the wave's first row by one division, then stepped row by row.
+    // All 16 row loads are issued before any arithmetic (the kernel is bound by bytes in flight);
+    // out-of-range rows read a clamped address and are zeroed afterwards.  x[t-1] is the
+    // neighbouring lane's sample (whole-wave DPP shift); lane 0 takes it from a scalar load.
+    uint32_t slot = (w * 64u + v * 16u) / lanes_per_slot, li = (w * 64u + v * 16u) % lanes_per_slot;
+    float2 xa[16], x0[16];
+    uint32_t okm = 0;                                       // bit k: row k exists
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; k++) {
+        const uint32_t g = w * 64u + v * 16u + k;
+        const bool ok = g < total_lanes;
+        const uint64_t a0 = ok ? (uint64_t)li * core + 64ull * t : 0ull;     // first sample of the row
+        const float2* x = iq + (uint64_t)(ok ? slot : 0u) * iq_stride;
+        const uint64_t ta = a0 + lane;
+        xa[k] = x[ta < n ? ta : (n - 1u)];
+        x0[k] = (a0 > 0ull && a0 <= n) ? x[a0 - 1u] : make_float2(0.0f, 0.0f);   // uniform address
+        okm |= (ok ? 1u : 0u) << k;
+        if (++li == lanes_per_slot) { li = 0u; slot++; }
+    }
+    {
+        uint32_t li2 = (w * 64u + v * 16u) % lanes_per_slot;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) {
+            const uint64_t ta = (uint64_t)li2 * core + 64ull * t + lane;
+            const float2 a = xa[k];
+            float2 p;
+            p.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x0[k].x), __builtin_bit_cast(int, a.x), 0x138, 0xf, 0xf, false));
+            p.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x0[k].y), __builtin_bit_cast(int, a.y), 0x138, 0xf, 0xf, false));
+            const float re = a.x * p.x + a.y * p.y;          // contraction is off: products round first
+            const float im = a.y * p.x - a.x * p.y;
+            float ang = fast_atan2f_tab(im, re, tab);
+            if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;          // non-finite input: defined as 0 (as the oracle)
+            if (!((okm >> k) & 1u) || ta >= n) ang = 0.0f;
+            tile[(v * 16u + k) * 65u + lane] = ang;
+            if (++li2 == lanes_per_slot) li2 = 0u;
         }
-        tile[r * 65u + lane] = ang;
     }
     __syncthreads();
     // S_j of the wave's 16 rows (oracle order): four threads per row sum 16 terms each in sequence,
