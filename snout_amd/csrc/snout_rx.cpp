@@ -543,7 +543,7 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
         snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);
     } else if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
         out->dominant_launches = 2;
-        snprintf(out->dominant_name, sizeof(out->dominant_name), "zb_discrim+zb_lanes");
+        snprintf(out->dominant_name, sizeof(out->dominant_name), "zb_discrim..zb_walk");
     } else {
         snprintf(out->dominant_name, sizeof(out->dominant_name), "btle_demod_corr");
     }

@@ -3,7 +3,7 @@
 // Replaces the GNU Radio receive flowgraph the reference spawns for `snout zigbee scan`
 // (snout/modulations/Zigbee/hackrf/Zigbee_rx/top_block.py:52-89):
 //   a4 quadrature_demod_cf(1)                       -> zb_discrim   (pointwise, HBM-bound)
-//   a5 x - single_pole_iir_filter_ff(0.00016)(x)    -> zb_lanes     (serial per lane, fp64 state)
+//   a5 x - single_pole_iir_filter_ff(0.00016)(x)    -> zb_mm        (serial per lane, fp64 state)
 //   a6 clock_recovery_mm_ff(2, .000225, .5, .03, .0002)              (serial feedback loop)
 //   a7 ieee802_15_4.packet_sink(10)                                  (serial FSM)
 //
