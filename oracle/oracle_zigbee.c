@@ -105,6 +105,7 @@ typedef struct {
     int preamble_cnt, chip_cnt, packet_byte, byte_index, packetlen, packetlen_cnt, payload_cnt;
     unsigned lqi, lqi_cnt;
     uint64_t trigger;   /* input sample index at which the first preamble symbol matched */
+    uint64_t sync;      /* `at` of the chip that completed the SFD (state 0 -> 1) */
     uint8_t pkt[128];
 } lane_t;
 
@@ -165,6 +166,7 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
             } else {
                 if (popc((s->shift & 0x7FFFFFFEu) ^ (kChipMap[10] & 0x7FFFFFFEu)) <= th) {
                     s->packet_byte |= 0xA;
+                    s->sync = at;
                     s->state = 1; s->packetlen_cnt = 0; s->packet_byte = 0; s->byte_index = 0;
                     s->lqi = 0; s->lqi_cnt = 0;
                 } else {
@@ -232,11 +234,12 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
  *
  * Sinks.  gr-ieee802-15-4's packet sink runs over the stitched stream once per lane: it starts
  * (searching, register cleared) ORACLE_ZB_SINK_WARM chips before the lane's first owned chip (or
- * at the start of the stream), reports the frames whose first preamble match falls on a chip the
- * lane owns, and stops when it is idle at or past the next lane's first owned chip.  Sinks that
- * start at different chips fall into step as soon as both are searching with a full register, so
- * every frame is reported by exactly one lane.  With core >= n (one lane) this is the reference's
- * sequential receiver.
+ * at the start of the stream) and stops when it is idle at or past the next lane's first owned
+ * chip.  Sinks that start at different chips fall into step as soon as both are searching with a
+ * full register; until then they may first match different symbols of one preamble, but they find
+ * the start-of-frame delimiter at the same chip, so a frame is reported by the lane that owns the
+ * chip completing its SFD (its sample_index is where THAT sink first matched the preamble).
+ * With core >= n (one lane) this is the reference's sequential receiver.
  */
 #define ORACLE_ZB_SINK_WARM 1024u
 
@@ -426,7 +429,9 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         for (uint64_t q = o[l] > ORACLE_ZB_SINK_WARM ? o[l] - ORACLE_ZB_SINK_WARM : 0; q < total; q++) {
             if (s.state == 0 && s.preamble_cnt == 0 && q >= o[l + 1]) break;   /* idle past the lane */
             const int done = sink_chip(&s, sb[q] ? 1.0f : -1.0f, q, threshold);  /* trigger = chip index */
-            if (done && s.trigger < o[l]) { enter_search(&s); continue; }        /* an earlier lane's frame */
+            /* a frame belongs to the lane that owns the chip completing its SFD: sinks may first
+             * match different preamble symbols, but they all find the SFD at the same chip */
+            if (done && (s.sync < o[l] || s.sync >= o[l + 1])) { enter_search(&s); continue; }
             if (done) {
                 if (*n_out < cap) {
                     snout_pkt* p = &out[*n_out];

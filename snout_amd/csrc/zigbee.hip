@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void zb_walk(
     enter_search(s);
     s.byte_index = s.packetlen = s.packetlen_cnt = s.payload_cnt = 0;
     s.lqi = s.lqi_cnt = 0; s.trigger = 0; s.c0 = s.c1 = s.c2 = 0; s.b_prev = s.b_last = 0;
-    uint32_t n_pk = 0;
+    uint32_t n_pk = 0, sync_q = 0;
     uint32_t q = own0 > kSinkWarmChips ? own0 - kSinkWarmChips : 0u;
     ChipReader rd;
     rd.open(sw, q);
@@ -768,14 +768,21 @@ __global__ __launch_bounds__(256) void zb_walk(
         rd.seek(qb);
         s.shift = rd.window32(qb);
         uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
+        const int state_before = s.state;
         const bool fin = sink_symbol(s, th, pb);
+        if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
         q = qb + 1u;
         if (fin) {
-            if (s.trigger >= own0) {                    // owned (the search never starts a frame past own1)
+            // Sinks may first match different preamble symbols but find the SFD at the same chip:
+            // the frame belongs to the lane that owns that chip.
+            if (sync_q >= own0 && sync_q < own1) {
                 if (n_pk < K) {
-                    // window start of the trigger chip: chip j of this lane, found in its tile records
-                    const uint32_t j = first_owned[g] + (s.trigger - own0);
-                    const uint32_t w = g >> 6, row = g & 63u;
+                    // window start of the trigger chip: chip j of the lane gt that owns it (this lane
+                    // or one before it), found in that lane's tile records
+                    uint32_t gt = g;
+                    while (s.trigger < offs[gt]) gt--;      // same channel: the sink started inside it
+                    const uint32_t j = first_owned[gt] + (s.trigger - offs[gt]);
+                    const uint32_t w = gt >> 6, row = gt & 63u;
                     uint32_t lo = 0, hi2 = nt;          // last tile with cstart <= j and nc > 0 reaching j
                     while (hi2 - lo > 1u) {
                         const uint32_t mid = (lo + hi2) >> 1;
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(256) void zb_walk(
                     const uint64_t top = i ? ~0ull << (64u - i) : 0ull;
                     const uint32_t rel = TR[tr_index(w, nt, lo, 8, row)] + i + (uint32_t)__popcll(dl & top) +
                                          2u * (uint32_t)__popcll(dh & top);
-                    const uint64_t cs = (uint64_t)li * core;
+                    const uint64_t cs = (uint64_t)(gt % lanes_per_slot) * core;
                     const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
                     snout_pkt* p = &stage[(size_t)g * K + n_pk];
                     const uint32_t len = (uint32_t)s.packetlen_cnt;
