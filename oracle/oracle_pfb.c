@@ -16,7 +16,7 @@
  * FFT: n = M2 n1 + n2, k = k1 + M1 k2;  M = 40: M1 = 8, M2 = 5;  M = 16: M1 = M2 = 4.
  *   A[n2][k1] = DFT_M1 over n1 (radix-2 DIT butterflies, exact +-1/+-i, sqrt(1/2) as one f32)
  *   B[n2][k1] = A[n2][k1] W_M^{n2 k1}        re = fmaf(a,c,-(b d)), im = fmaf(a,d,b c)
- *   X[k1 + M1 k2] = DFT_M2 over n2           M2 = 5: direct, fmaf chain; M2 = 4: butterflies
+ *   X[k1 + M1 k2] = DFT_M2 over n2           M2 = 5: real-factor form (dft5 below); M2 = 4: butterflies
  */
 #include <math.h>
 #include <stdint.h>
@@ -60,20 +60,25 @@ static void dft8(const cf a[8], cf X[8])
     for (int k = 0; k < 4; k++) { X[k] = cadd(E[k], T[k]); X[k + 4] = csub(E[k], T[k]); }
 }
 
+/* 5-point DFT by its real-factor symmetry (36 operations instead of 80), fixed order:
+ *   t1 = b1+b4, t2 = b2+b3, t3 = b1-b4, t4 = b2-b3,  X0 = (b0+t1)+t2
+ *   a1 = fma(C2,t2, fma(C1,t1,b0)),  a2 = fma(C1,t2, fma(C2,t1,b0))         C = cos(2 pi j/5)
+ *   s1 = fma(S2,t4, S1*t3),          s2 = fma(-S1,t4, S2*t3)                S = sin(2 pi j/5)
+ *   X1 = a1 - i s1, X4 = a1 + i s1, X2 = a2 - i s2, X3 = a2 + i s2 */
 static void dft5(const cf b[5], cf X[5])
 {
-    for (int k = 0; k < 5; k++) {
-        cf acc = b[0];
-        for (int n = 1; n < 5; n++) {
-            const int j = (n * k) % 5;
-            const float wr = kTw5[2 * j], wi = kTw5[2 * j + 1];
-            acc.re = fmaf(b[n].re, wr, acc.re);
-            acc.re = fmaf(-b[n].im, wi, acc.re);
-            acc.im = fmaf(b[n].re, wi, acc.im);
-            acc.im = fmaf(b[n].im, wr, acc.im);
-        }
-        X[k] = acc;
-    }
+    const float C1 = kTw5[2], C2 = kTw5[4], S1 = -kTw5[3], S2 = -kTw5[5];
+    const cf t1 = cadd(b[1], b[4]), t2 = cadd(b[2], b[3]), t3 = csub(b[1], b[4]), t4 = csub(b[2], b[3]);
+    cf a1, a2, s1, s2;
+    X[0] = cadd(cadd(b[0], t1), t2);
+    a1.re = fmaf(C2, t2.re, fmaf(C1, t1.re, b[0].re)); a1.im = fmaf(C2, t2.im, fmaf(C1, t1.im, b[0].im));
+    a2.re = fmaf(C1, t2.re, fmaf(C2, t1.re, b[0].re)); a2.im = fmaf(C1, t2.im, fmaf(C2, t1.im, b[0].im));
+    s1.re = fmaf(S2, t4.re, S1 * t3.re);  s1.im = fmaf(S2, t4.im, S1 * t3.im);
+    s2.re = fmaf(-S1, t4.re, S2 * t3.re); s2.im = fmaf(-S1, t4.im, S2 * t3.im);
+    X[1].re = a1.re + s1.im; X[1].im = a1.im - s1.re;
+    X[4].re = a1.re - s1.im; X[4].im = a1.im + s1.re;
+    X[2].re = a2.re + s2.im; X[2].im = a2.im - s2.re;
+    X[3].re = a2.re - s2.im; X[3].im = a2.im + s2.re;
 }
 
 static void fft40(const cf* u, cf* X)

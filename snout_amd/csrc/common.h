@@ -111,7 +111,7 @@ void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fi
 struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
-    uint32_t grid_blocks = 768;      // persistent grid (256 CUs x 3 workgroups)
+    uint32_t grid_blocks = 768;      // persistent grid (256 CUs x 3 workgroups: 128 VGPRs, 36 KB LDS)
     DevBuf d_proto, d_tw, d_tw5, d_y;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     int init(uint32_t M);

@@ -65,22 +65,25 @@ __device__ __forceinline__ void dft8(const cf a[8], cf X[8])
     for (int k = 0; k < 4; k++) { X[k] = cadd(E[k], T[k]); X[k + 4] = csub(E[k], T[k]); }
 }
 
+// 5-point DFT by its real-factor symmetry, the operation order of oracle_pfb.c.
 __device__ __forceinline__ void dft5(const cf b[5], cf X[5], const float* __restrict__ tw5)
 {
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        cf acc = b[0];
-#pragma unroll
-        for (int n = 1; n < 5; n++) {
-            const int j = (n * k) % 5;
-            const float wr = tw5[2 * j], wi = tw5[2 * j + 1];
-            acc.re = __builtin_fmaf(b[n].re, wr, acc.re);
-            acc.re = __builtin_fmaf(-b[n].im, wi, acc.re);
-            acc.im = __builtin_fmaf(b[n].re, wi, acc.im);
-            acc.im = __builtin_fmaf(b[n].im, wr, acc.im);
-        }
-        X[k] = acc;
-    }
+    const float C1 = tw5[2], C2 = tw5[4], S1 = -tw5[3], S2 = -tw5[5];
+    const cf t1 = cadd(b[1], b[4]), t2 = cadd(b[2], b[3]), t3 = csub(b[1], b[4]), t4 = csub(b[2], b[3]);
+    cf a1, a2, s1, s2;
+    X[0] = cadd(cadd(b[0], t1), t2);
+    a1.re = __builtin_fmaf(C2, t2.re, __builtin_fmaf(C1, t1.re, b[0].re));
+    a1.im = __builtin_fmaf(C2, t2.im, __builtin_fmaf(C1, t1.im, b[0].im));
+    a2.re = __builtin_fmaf(C1, t2.re, __builtin_fmaf(C2, t1.re, b[0].re));
+    a2.im = __builtin_fmaf(C1, t2.im, __builtin_fmaf(C2, t1.im, b[0].im));
+    s1.re = __builtin_fmaf(S2, t4.re, S1 * t3.re);
+    s1.im = __builtin_fmaf(S2, t4.im, S1 * t3.im);
+    s2.re = __builtin_fmaf(-S1, t4.re, S2 * t3.re);
+    s2.im = __builtin_fmaf(-S1, t4.im, S2 * t3.im);
+    X[1] = cf{a1.re + s1.im, a1.im - s1.re};
+    X[4] = cf{a1.re - s1.im, a1.im + s1.re};
+    X[2] = cf{a2.re + s2.im, a2.im - s2.re};
+    X[3] = cf{a2.re - s2.im, a2.im + s2.re};
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
@@ -92,110 +95,119 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <int M> struct PfbGeom;
-template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320, NTF = 384; };
-template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256, NTF = 256; };
+// waves per SIMD the register allocator must leave room for: 4 -> at most 128 VGPRs, three
+// 320-thread workgroups per CU
+#ifndef SNOUT_PFB_WPE
+#define SNOUT_PFB_WPE 4
+#endif
 
-// FUSED (BTLE, M = 40): instead of writing 16 B of channel IQ per input sample, the tile keeps its
-// outputs in LDS, computes 4 extra output times as a halo and emits the BTLE hard bits
-//   bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m])
-// of all 40 channels straight into the bit planes the correlator reads (0.25 B per input sample).
+template <int M> struct PfbGeom;
+template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320; };
+template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256; };
+
+// One workgroup walks a contiguous range of tiles of T output times.  Consecutive tiles share
+// (MP - D) input samples: they stay in LDS (moved to the front through registers), only T D new
+// samples are fetched per tile, one tile ahead, into registers.
+//
+// FUSED (BTLE, M = 40): instead of writing 16 B of channel IQ per input sample the tile keeps its
+// outputs in LDS and emits the BTLE hard bits  bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m])  of all 40
+// channels straight into the bit planes the correlator reads (0.25 B per input sample).  Thread
+// (channel, phase) decides 15 symbols of the tile at once and the 16th when the next tile's first
+// outputs exist (it carries its last sample and the pending 15 bits in registers); the workgroup
+// therefore also computes the tile after its range, without emitting that tile's own bits.
 template <int M, bool FUSED>
-__global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_channelize(
-    const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles,
+__global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(SNOUT_PFB_WPE))) void pfb_channelize(
+    const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
     uint64_t plane_stride)
 {
     using G = PfbGeom<M>;
-    constexpr int T = G::T, M1 = G::M1, M2 = G::M2, D = M / 2, P = 16;
-    constexpr int NT = FUSED ? G::NTF : G::NT;     // threads in the workgroup
-    constexpr int NFIR = G::NT;                    // threads with a FIR role
-    constexpr int TH = FUSED ? T + 4 : T;          // output times computed per tile (halo for demod)
-    constexpr int SPAN = (TH - 1) * D + M * P;     // input samples one tile needs
+    constexpr int T = G::T, M1 = G::M1, M2 = G::M2, D = M / 2, P = 16, NT = G::NT;
+    constexpr int SPAN = (T - 1) * D + M * P;      // input samples one tile needs
+    constexpr int NEW = T * D;                     // of which new per tile
     constexpr int ROW = M + 1;                     // padded LDS row, complex
-    constexpr int YROW = TH + 1;                   // fused: channel-major tile, padded
-    static_assert(SPAN % 2 == 0 && (T * D) % 2 == 0, "16-byte staging needs even sample counts");
-    constexpr int SPAN4 = SPAN / 2;                // the span as 16-byte pairs of samples
-    constexpr int NPRE = (SPAN4 + NT - 1) / NT;    // pairs each thread stages per tile
-    constexpr int XB = SPAN > TH * ROW ? SPAN : TH * ROW;
-    constexpr int UB = (FUSED && M * YROW > TH * ROW) ? M * YROW : TH * ROW;
-    __shared__ float2 xb[XB];                      // input span, later the twiddled half-transform
-    __shared__ float2 ub[UB];                      // FIR outputs u_m[r]; fused: later y_k[m]
+    static_assert(SPAN % 2 == 0 && NEW % 2 == 0, "16-byte staging needs even sample counts");
+    constexpr int SPAN4 = SPAN / 2, NEW4 = NEW / 2, OV4 = SPAN4 - NEW4;   // in pairs of samples
+    static_assert(NEW4 % NT == 0 && OV4 <= NT, "staging shape");
+    constexpr int NPRE = NEW4 / NT;                // new pairs each thread stages per tile
+    __shared__ float2 xs[SPAN];                    // input span of the current tile
+    __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
     __shared__ float tw_s[2 * M + 10];
-    float2* xs = xb;
-    float2* bs = xb;
-    float2* us = ub;
-    float2* ys = ub;
 
     const int t = threadIdx.x;
     for (int i = t; i < 2 * M; i += NT) tw_s[i] = twM[i];
     if (t < 10) tw_s[2 * M + t] = tw5g[t];
     // FIR role of this thread: (branch r, output parity e, group grp); taps live in registers
     const int r = t % M, e = (t / M) & 1, grp = t / (2 * M);
-    constexpr int NGRP = NFIR / (2 * M);           // groups of 8 outputs per parity
     float h[P];
 #pragma unroll
-    for (int p = 0; p < P; p++) h[p] = (t < NFIR) ? proto[r + p * M] : 0.0f;
+    for (int p = 0; p < P; p++) h[p] = proto[r + p * M];
 
-    // The workgroup walks tiles blockIdx.x, +gridDim.x, ...; the input of the NEXT tile is fetched
-    // into registers while the current one is computed.
-    float4 pre[NPRE];
+    const uint32_t t_begin = blockIdx.x * tiles_per_wg;
+    uint32_t t_end = t_begin + tiles_per_wg;
+    if (t_end > n_tiles) t_end = n_tiles;
+    if (t_begin >= t_end) return;
+    // fused: one more tile (if it exists) supplies the samples the last symbols are compared with
+    const uint32_t t_last = (FUSED && t_end < n_tiles) ? t_end + 1u : t_end;
+
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    auto fetch = [&](uint32_t tile) {
-        const uint64_t in0 = (uint64_t)tile * T * D;            // even -> 16-byte aligned
-#pragma unroll
-        for (int k = 0; k < NPRE; k++) {
-            const int i = t + k * NT;
-            const uint64_t g = in0 + 2ull * (uint64_t)i;         // first sample of the pair
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (i < SPAN4) {
-                if (g + 1 < n) v = x4[g >> 1];
-                else if (g < n) { const float2 a = x[g]; v.x = a.x; v.y = a.y; }
-            }
-            pre[k] = v;
-        }
+    auto load_pair = [&](uint64_t g) -> float4 {               // samples g, g+1 (g even), zero past n
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (g + 1 < n) v = x4[g >> 1];
+        else if (g < n) { const float2 a = x[g]; v.x = a.x; v.y = a.y; }
+        return v;
     };
-    uint32_t tile = blockIdx.x;
-    if (tile < n_tiles) fetch(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t m0 = (uint64_t)tile * T;
-        // ---- 1. stage the prefetched input span
+    // first tile: the whole span; later tiles: the overlap comes from LDS (keep), the rest from pre
+    float4 keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre[NPRE];
+    {
+        const uint64_t in0 = (uint64_t)t_begin * NEW;            // even -> 16-byte aligned
+        if (t < OV4) keep = load_pair(in0 + 2ull * (uint64_t)t);
 #pragma unroll
-        for (int k = 0; k < NPRE; k++) {
-            const int i = t + k * NT;
-            if (i < SPAN4) reinterpret_cast<float4*>(xs)[i] = pre[k];
-        }
-        lds_barrier();
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in0 + 2ull * (uint64_t)(OV4 + t + k * NT));
+    }
+    // fused: state of thread (channel k, phase j) across tiles
+    float2 carry = make_float2(0.0f, 0.0f);        // y_k[m0 - 4 + j] of the previous tile
+    uint32_t pend = 0;                             // its 15 decided bits
+    bool have_prev = false;
 
-        // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product.
-        //      Fused: the last group also produces the 2 extra outputs per parity of the halo.
-        if (t < NFIR) {
-            constexpr int NI = FUSED ? 10 : 8;
-            const int n_i = (FUSED && grp == NGRP - 1) ? 10 : 8;
+    for (uint32_t tile = t_begin; tile < t_last; tile++) {
+        const uint64_t m0 = (uint64_t)tile * T;
+        // ---- 1. stage: overlap to the front, new samples behind it
+        if (t < OV4) reinterpret_cast<float4*>(xs)[t] = keep;
+#pragma unroll
+        for (int k = 0; k < NPRE; k++) reinterpret_cast<float4*>(xs)[OV4 + t + k * NT] = pre[k];
+        lds_barrier();
+        if (tile + 1u < t_last) {
+            const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
+#pragma unroll
+            for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in1 + 2ull * (uint64_t)(t + k * NT));
+        }
+
+        // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product
+        {
             const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
-            float2 w[NI + P - 1];
+            float2 w[8 + P - 1];
 #pragma unroll
-            for (int q = 0; q < NI + P - 1; q++)
-                w[q] = (q < n_i + P - 1) ? xs[base + q * M] : make_float2(0.0f, 0.0f);
+            for (int q = 0; q < 8 + P - 1; q++) w[q] = xs[base + q * M];
 #pragma unroll
-            for (int i = 0; i < NI; i++) {
+            for (int i = 0; i < 8; i++) {
                 float ar = 0.0f, ai = 0.0f;
 #pragma unroll
                 for (int p = 0; p < P; p++) {
                     ar = __builtin_fmaf(h[p], w[i + p].x, ar);
                     ai = __builtin_fmaf(h[p], w[i + p].y, ai);
                 }
-                const int m = e + 2 * (8 * grp + i);
-                if (i < n_i) us[m * ROW + r] = make_float2(ar, ai);
+                us[(e + 2 * (8 * grp + i)) * ROW + r] = make_float2(ar, ai);
             }
         }
-        lds_barrier();        // xs is dead from here: bs reuses its storage
+        if (t < OV4) keep = reinterpret_cast<const float4*>(xs)[NEW4 + t];   // next tile's overlap
+        lds_barrier();
 
-        // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}
-        for (int it = t; it < TH * M2; it += NT) {
-            const int m = it % TH, n2 = it / TH;
+        // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}; in place:
+        //      slot M2 k1 + n2 of row m receives B[n2][k1]
+        for (int it = t; it < T * M2; it += NT) {
+            const int m = it % T, n2 = it / T;
             cf a[M1], A[M1];
 #pragma unroll
             for (int n1 = 0; n1 < M1; n1++) {
@@ -207,15 +219,16 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
             for (int k1 = 0; k1 < M1; k1++) {
                 const int j = (n2 * k1) % M;
                 const cf v = j ? cmul_tw(A[k1], tw_s[2 * j], tw_s[2 * j + 1]) : A[k1];
-                bs[m * ROW + n2 * M1 + k1] = make_float2(v.re, v.im);
+                us[m * ROW + M2 * k1 + n2] = make_float2(v.re, v.im);
             }
         }
-        lds_barrier();        // us is dead from here (fused: ys reuses its storage)
+        lds_barrier();
 
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
-        //      A thread owns two consecutive output times so each global store is 16 bytes.
-        for (int it = t; it < (TH / 2) * M1; it += NT) {
-            const int mp = it % (TH / 2), k1 = it / (TH / 2);
+        //      Fused: in place, channel k = k1 + M1 k2 ends up in slot M2 k1 + k2 of row m.
+        //      Otherwise a thread owns two consecutive output times so each global store is 16 B.
+        for (int it = t; it < (T / 2) * M1; it += NT) {
+            const int mp = it % (T / 2), k1 = it / (T / 2);
             cf Y0[M2], Y1[M2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++) {
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
                 cf b[M2];
 #pragma unroll
                 for (int n2 = 0; n2 < M2; n2++) {
-                    const float2 v = bs[m * ROW + n2 * M1 + k1];
+                    const float2 v = us[m * ROW + M2 * k1 + n2];
                     b[n2] = cf{v.x, v.y};
                 }
                 if (h2 == 0) { if constexpr (M2 == 5) dft5(b, Y0, &tw_s[2 * M]); else dft4(b, Y0); }
@@ -236,8 +249,8 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
                 cf v1 = Y1[k2];
                 if (k & 1) { v1.re = -v1.re; v1.im = -v1.im; }
                 if constexpr (FUSED) {
-                    ys[k * YROW + 2 * mp] = make_float2(Y0[k2].re, Y0[k2].im);
-                    ys[k * YROW + 2 * mp + 1] = make_float2(v1.re, v1.im);
+                    us[(2 * mp) * ROW + M2 * k1 + k2] = make_float2(Y0[k2].re, Y0[k2].im);
+                    us[(2 * mp + 1) * ROW + M2 * k1 + k2] = make_float2(v1.re, v1.im);
                 } else {
                     float2* dst = &y[(uint64_t)k * y_stride + mg];
                     if (mg + 1 < n_out) *reinterpret_cast<float4*>(dst) = make_float4(Y0[k2].re, Y0[k2].im, v1.re, v1.im);
@@ -245,33 +258,43 @@ __global__ __launch_bounds__(FUSED ? PfbGeom<M>::NTF : PfbGeom<M>::NT) void pfb_
                 }
             }
         }
-        lds_barrier();        // bs (= xs) is overwritten by the next tile's input
 
         if constexpr (FUSED) {
-            // ---- 4. hard bits of the tile's T samples of every channel.  A 16-lane group owns
-            //      (channel k, phase j): lane s of it decides symbol s, i.e. sample m = 4 s + j; the
-            //      ballot packs the 16 decisions, one lane stores them as the tile's quarter of the
-            //      64-symbol plane word (planes: [slot k][word g][phase j] u64, bit l = sample 256g+4l+j).
-            const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;          // bits exist for m < n_out-4
-            const uint32_t lane = (uint32_t)t & 63u, sym = lane & 15u, q = lane >> 4;
-            const uint64_t g = m0 >> 8;                                  // plane word index
-            const uint32_t quarter = (uint32_t)((m0 & 255u) >> 6);       // which 16 symbols of it
-            for (int grp0 = (t >> 6) * 4; grp0 < M * 4; grp0 += (NT / 64) * 4) {
-                const int gi = grp0 + (int)q;                             // (k, j) group of this lane
-                const int k = gi >> 2, j = gi & 3;
-                const int m = 4 * (int)sym + j;
-                bool bit = false;
-                if (gi < M * 4) {
-                    const float2 a = ys[k * YROW + m], b4 = ys[k * YROW + m + 4];
-                    bit = ((a.x * b4.y) > (b4.x * a.y)) && (m0 + (uint64_t)m < nbits);
+            lds_barrier();
+            // ---- 4. hard bits.  Thread <-> (channel k, phase j), samples m = 4 s + j: symbol 15 of
+            //      the previous tile (its sample is carried in a register) completes that tile's
+            //      quarter of the 64-symbol plane word, which is stored now; symbols 0..14 of this
+            //      tile wait for the next one.
+            //      planes: [slot k][word g][phase j] u64, bit l = sample 256 g + 4 l + j.
+            if (t < M * 4) {
+                const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;      // bits exist for m < n_out-4
+                const int k = t >> 2, j = t & 3;
+                const float2* col = &us[M2 * (k % M1) + (k / M1)];       // channel k of row 0
+                float2 a = col[j * ROW];
+                if (have_prev) {
+                    const uint64_t mprev = m0 - 4u + (uint64_t)j;        // sample of the carried value
+                    const bool bit = ((carry.x * a.y) > (a.x * carry.y)) && (mprev < nbits);
+                    const uint64_t mq = m0 - (uint64_t)T;                // first sample of the previous tile
+                    planes16[((uint64_t)k * plane_stride + (mq >> 8) * 4u + (uint32_t)j) * 4u +
+                             (uint32_t)((mq & 255u) >> 6)] = (uint16_t)(pend | ((bit ? 1u : 0u) << 15));
                 }
-                const uint64_t mask = __ballot(bit);
-                if (sym == 0 && gi < M * 4)
-                    planes16[((uint64_t)k * plane_stride + g * 4u + (uint32_t)j) * 4u + quarter] =
-                        (uint16_t)(mask >> (16u * q));
+                uint32_t bits = 0;
+#pragma unroll
+                for (int sy = 0; sy < 15; sy++) {
+                    const float2 b4 = col[(4 * sy + 4 + j) * ROW];
+                    const bool bit = ((a.x * b4.y) > (b4.x * a.y)) && (m0 + (uint64_t)(4 * sy + j) < nbits);
+                    bits |= (bit ? 1u : 0u) << sy;
+                    a = b4;
+                }
+                pend = bits;
+                carry = a;                                               // y_k[m0 + 60 + j]
+                have_prev = true;
+                if (tile + 1u == n_tiles)                                // no later tile: symbol 15 has no partner
+                    planes16[((uint64_t)k * plane_stride + (m0 >> 8) * 4u + (uint32_t)j) * 4u +
+                             (uint32_t)((m0 & 255u) >> 6)] = (uint16_t)pend;
             }
-            lds_barrier();    // ys (= us) is overwritten by the next tile's FIR
         }
+        // the next tile's FIR writes us only after the staging barrier, i.e. after every read above
     }
 }
 
@@ -317,23 +340,25 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
     if (!planes16) { if (int rc = d_y.ensure(y_stride * M * 8u)) return rc; }
     if (n_out == 0) return 0;
     SNOUT_HIP(hipEventRecord(ev_k0, st));
-    // persistent workgroups: 3 per CU (LDS-limited), each walks tiles with a stride of the grid
+    // persistent workgroups (3 per CU by registers), each walks a contiguous range of tiles
     if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
+        const uint32_t tpw = cdiv(n_tiles, grid_blocks), nwg = cdiv(n_tiles, tpw);
         if (planes16)
-            hipLaunchKernelGGL((pfb_channelize<40, true>), dim3(std::min(n_tiles, grid_blocks)),
-                               dim3(PfbGeom<40>::NTF), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
+            hipLaunchKernelGGL((pfb_channelize<40, true>), dim3(nwg), dim3(PfbGeom<40>::NT), 0, st,
+                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
                                d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
                                (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
-            hipLaunchKernelGGL((pfb_channelize<40, false>), dim3(std::min(n_tiles, grid_blocks)),
-                               dim3(PfbGeom<40>::NT), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
+            hipLaunchKernelGGL((pfb_channelize<40, false>), dim3(nwg), dim3(PfbGeom<40>::NT), 0, st,
+                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
                                d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
                                d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
-        hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(std::min(n_tiles, grid_blocks)),
-                           dim3(PfbGeom<16>::NT), 0, st, (const float2*)d_iq, n, n_out, n_tiles,
+        const uint32_t tpw = cdiv(n_tiles, grid_blocks), nwg = cdiv(n_tiles, tpw);
+        hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st,
+                           (const float2*)d_iq, n, n_out, n_tiles, tpw,
                            d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
                            d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     }

@@ -1,0 +1,47 @@
+"""CPU: the channelizer oracle (oracle/oracle_pfb.c) against an independent float64 numpy statement
+of the same definition, and the properties that make it a channelizer."""
+import numpy as np
+import pytest
+
+
+def _direct(x, h, M):
+    D, L = M // 2, M * 16
+    n_out = (x.size - L) // D + 1
+    y = np.zeros((M, n_out), dtype=np.complex128)
+    r = np.arange(M)
+    for m in range(n_out):
+        seg = x[m * D:m * D + L].astype(np.complex128) * h
+        u = seg.reshape(16, M).sum(axis=0)                      # u_m[r] = sum_p h[r+pM] x[mD+r+pM]
+        X = np.fft.fft(u)                                       # sum_r u[r] e^{-2 pi i k r / M}
+        y[:, m] = X * ((-1.0) ** (r * m))
+    return y
+
+
+@pytest.mark.parametrize("M", [40, 16])
+def test_oracle_matches_float64_definition(oracle, M):
+    rng = np.random.default_rng(M)
+    n = M * 16 + (M // 2) * 200 + 7
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    h = oracle.pfb_proto(M).astype(np.float64)
+    got = oracle.pfb(x, M)
+    want = _direct(x, h, M)
+    assert got.shape == want.shape == (M, oracle.pfb_nout(n, M))
+    scale = np.abs(want).max()
+    assert np.max(np.abs(got - want)) <= 2e-6 * scale          # f32 arithmetic, ~700 terms per output
+
+
+@pytest.mark.parametrize("M", [40, 16])
+def test_tone_lands_in_its_bin(oracle, M):
+    n = M * 16 + (M // 2) * 400
+    t = np.arange(n)
+    for k in (0, 3, M // 2, M - 1):
+        x = np.exp(2j * np.pi * k * t / M).astype(np.complex64)
+        p = (np.abs(oracle.pfb(x, M)) ** 2).mean(axis=1)
+        assert np.argmax(p) == k
+        others = np.delete(p, [k, (k - 1) % M, (k + 1) % M])
+        assert others.max() < 1e-6 * p[k]                        # > 60 dB to non-adjacent bins
+
+
+def test_short_input_has_no_output(oracle):
+    assert oracle.pfb_nout(639, 40) == 0 and oracle.pfb_nout(640, 40) == 1 and oracle.pfb_nout(660, 40) == 2
+    assert oracle.pfb(np.zeros(100, np.complex64), 16).shape == (16, 0)
