@@ -589,6 +589,23 @@ __device__ __forceinline__ int decode_chips(SinkState& s, uint32_t th)
     return 0xFF;
 }
 
+// The nearest of the 16 chip words to a 32-chip window and its distance (what decode_chips
+// computes, as a pure function): result = nibble | distance << 8.
+__device__ __forceinline__ uint32_t nearest_word(uint32_t window)
+{
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; i++) {
+        const uint32_t d = chip_dist(window, kChipMap[i]);
+        const uint32_t a = d * 8u + i, b = d * 8u + (7u - i);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    const uint32_t d_lo = kmin >> 3, d_hi = 30u - (kmax >> 3);
+    const bool low = d_lo <= d_hi;
+    return (low ? (kmin & 7u) : 8u + (7u - (kmax & 7u))) | ((low ? d_lo : d_hi) << 8);
+}
+
 // One byte of the reflected CCITT CRC (poly 0x8408), closed form of the eight shift steps.
 __device__ __forceinline__ uint32_t crc16_step(uint32_t c, uint32_t byte)
 {
@@ -762,16 +779,58 @@ __global__ __launch_bounds__(256) void zb_walk(
             s.trigger = q - 1u;
             continue;
         }
-        // inside a (candidate) frame: jump to the next symbol boundary
-        const uint32_t qb = q + 31u;                    // q is the first chip of the symbol
-        if (qb >= total) break;                         // the stream ends inside the frame
-        rd.seek(qb);
-        s.shift = rd.window32(qb);
-        uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
-        const int state_before = s.state;
-        const bool fin = sink_symbol(s, th, pb);
-        if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
-        q = qb + 1u;
+        // inside a (candidate) frame
+        bool fin = false, stepped = false;
+        if (s.state == 2 && s.byte_index == 0 && s.packetlen - s.payload_cnt >= 4 && q + 255u < total) {
+            // Payload, at least four bytes to go: decode eight symbols at once.  Their windows come
+            // straight from memory (eight independent 16-byte loads) and the eight nearest-word
+            // searches are independent, so a lane that is alone in a long frame is not bound by the
+            // latency of one symbol after the other.  If any of the eight is further than the
+            // threshold from every word, the one-symbol path below takes over (same result).
+            uint32_t nw[8];
+            uint32_t worst = 0;
+#pragma unroll
+            for (uint32_t j2 = 0; j2 < 8u; j2++) {
+                const uint32_t qe = q + 31u + 32u * j2;             // last chip of symbol j2
+                const uint32_t wi2 = qe >> 6, sh = 63u - (qe & 63u);
+                const uint64_t cur = sw[wi2], prv = wi2 ? sw[wi2 - 1u] : 0ull;
+                uint64_t xw = cur >> sh;
+                if (sh > 32u) xw |= prv << (64u - sh);
+                nw[j2] = nearest_word((uint32_t)xw);
+                worst = (nw[j2] >> 8) > worst ? (nw[j2] >> 8) : worst;
+            }
+            if (worst < th) {
+                uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
+#pragma unroll
+                for (uint32_t b2 = 0; b2 < 4u; b2++) {
+#pragma unroll
+                    for (uint32_t h2 = 0; h2 < 2u; h2++)
+                        if (s.lqi_cnt < 8) { s.lqi += 32 - (nw[2u * b2 + h2] >> 8); s.lqi_cnt++; }
+                    const uint32_t byte = (nw[2u * b2] & 15u) | ((nw[2u * b2 + 1u] & 15u) << 4);
+                    if (pb) pb[s.packetlen_cnt] = (uint8_t)byte;
+                    s.c2 = s.c1; s.c1 = s.c0; s.c0 = crc16_step(s.c0, byte);
+                    s.b_prev = s.b_last; s.b_last = byte;
+                    s.packetlen_cnt++;
+                    s.payload_cnt++;
+                }
+                s.packet_byte = (int)s.b_last;
+                q += 256u;
+                fin = s.payload_cnt >= s.packetlen;
+                stepped = true;
+            }
+        }
+        if (!stepped) {
+            // one symbol: jump to the next symbol boundary
+            const uint32_t qb = q + 31u;                    // q is the first chip of the symbol
+            if (qb >= total) break;                         // the stream ends inside the frame
+            rd.seek(qb);
+            s.shift = rd.window32(qb);
+            uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
+            const int state_before = s.state;
+            fin = sink_symbol(s, th, pb);
+            if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
+            q = qb + 1u;
+        }
         if (fin) {
             // Sinks may first match different preamble symbols but find the SFD at the same chip:
             // the frame belongs to the lane that owns that chip.
