@@ -22,8 +22,13 @@ ZIGBEE_OVERLAP_CH = 17024 + 2048
 
 
 class ShardedScan:
+    """``handles`` > 1 keeps that many receiver handles, each on its own stream, and deals the
+    segments to them in turn: short segments leave most of the GPU idle inside the latency-bound
+    kernels (a 2^24-sample Zigbee segment is 128 waves of clock recovery), and independent handles
+    let consecutive segments overlap."""
+
     def __init__(self, proto: int, n_channels: int = 1, channel: int = 37, seg_len: int = 1 << 24,
-                 device: int = -1, **rx_kw):
+                 device: int = -1, handles: int = 1, **rx_kw):
         self.proto = proto
         self.n_channels = n_channels
         self.decim = n_channels // 2 if n_channels > 1 else 1
@@ -32,30 +37,101 @@ class ShardedScan:
         self.overlap = ov_ch * self.decim + self.pfb_taps            # in input samples
         step = 2 * self.decim                                         # keep PFB phase parity aligned
         self.seg_len = max(step, seg_len // step * step)
-        self.rx = SnoutRx(proto=proto, channel=channel, n_channels=n_channels, device=device, **rx_kw)
+        self.rxs = [SnoutRx(proto=proto, channel=channel, n_channels=n_channels, device=device, **rx_kw)
+                    for _ in range(max(1, handles))]
+        self.rx = self.rxs[0]
+        self._streams = None
 
     def close(self):
-        self.rx.close()
+        for rx in self.rxs:
+            rx.close()
 
-    def run(self, n_total: int, source: Callable[[int, int], "object"], group=None,
-            gather_device=None) -> Optional[np.ndarray]:
+    def my_segments(self, n_total: int, group=None):
         import torch.distributed as tdist
         world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         rank = tdist.get_rank(group) if tdist.is_initialized() else 0
-        segs = sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world)
-        parts, pending = [], []
-        for (a, b) in segs:
-            x = source(a, b)
-            pending.append(x)                                   # keep the tensor alive until collected
-            self.rx.submit(x, first_sample_index=a // self.decim)
-            if len(pending) == 2:
-                parts.append(self.rx.collect())
-                pending.pop(0)
-        while pending:
-            parts.append(self.rx.collect())
-            pending.pop(0)
+        return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world)
+
+    # ---- a scan as a sequence of steps, so that several scans can share a GPU (run_concurrent)
+    def start(self, n_total: int, source: Callable[[int, int], "object"], group=None) -> None:
+        import torch
+        if self._streams is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._streams = [torch.cuda.Stream(device=dev) for _ in self.rxs]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())               # the capture was produced on this stream
+        for st in self._streams:
+            st.wait_event(ready)
+        self._segs = self.my_segments(n_total, group)
+        self._source = source
+        self._next = 0                  # next segment to submit
+        self._done = 0                  # segments collected
+        self._alive = {}                # segment index -> tensor (kept until collected)
+        self._parts = []
+
+    def active(self) -> bool:
+        return self._done < len(self._segs)
+
+    def step(self) -> None:
+        """Submit the next segment if a slot is free (two per handle), else collect the oldest."""
+        import torch
+        H = len(self.rxs)
+        if self._next < len(self._segs) and self._next - self._done < 2 * H:
+            j = self._next
+            a, b = self._segs[j]
+            st = self._streams[j % H]
+            with torch.cuda.stream(st):
+                x = self._source(a, b)
+                self.rxs[j % H].submit(x, first_sample_index=a // self.decim, stream=st.cuda_stream)
+            self._alive[j] = x
+            self._next += 1
+        elif self._done < self._next:
+            j = self._done
+            self._parts.append(self.rxs[j % H].collect())      # segments of a handle complete in order
+            del self._alive[j]
+            self._done += 1
+
+    def finish(self, parts, group=None, gather_device=None) -> Optional[np.ndarray]:
+        """Gather this rank's records on rank 0 and drop the duplicates of the overlaps."""
+        import torch.distributed as tdist
+        world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         mine = np.concatenate(parts) if parts else np.zeros(0, dtype=PKT_DTYPE)
         allrec = sdist.gather_records(mine, gather_device, group) if world > 1 else mine
         if allrec is None:
             return None
         return sdist.dedup_records(allrec, tol=0 if self.proto == PROTO_BTLE else 8 * 64 + 8)
+
+    def run(self, n_total: int, source: Callable[[int, int], "object"], group=None,
+            gather_device=None, stats: Optional[dict] = None) -> Optional[np.ndarray]:
+        """``stats`` (optional dict) receives ``device_s``: wall time of the submit/collect loop, i.e.
+        until this rank's last records are in host memory, and ``post_s``: gather + sort + dedup."""
+        import time
+        t0 = time.perf_counter()
+        self.start(n_total, source, group)
+        while self.active():
+            self.step()
+        t1 = time.perf_counter()
+        out = self.finish(self._parts, group, gather_device)
+        if stats is not None:
+            stats["device_s"], stats["post_s"] = t1 - t0, time.perf_counter() - t1
+        return out
+
+
+def run_concurrent(scans, n_totals, sources, group=None, gather_device=None, stats: Optional[dict] = None):
+    """SURVEY §8d cfg #5: several wideband scans (e.g. BTLE 40 channels and Zigbee 16 channels, each
+    with its own capture) share every GPU.  Every handle of every scan has its own stream and the
+    scans take turns submitting / collecting segments, so the kernels of one fill the gaps of the
+    other.  Returns one record array per scan (rank 0; None elsewhere)."""
+    import time
+    t0 = time.perf_counter()
+    for sc, n, src in zip(scans, n_totals, sources):
+        sc.start(n, src, group)
+    while any(sc.active() for sc in scans):
+        for sc in scans:
+            if sc.active():
+                sc.step()
+    t1 = time.perf_counter()
+    out = [sc.finish(sc._parts, group, gather_device) for sc in scans]
+    if stats is not None:
+        stats["device_s"], stats["post_s"] = t1 - t0, time.perf_counter() - t1
+    return out

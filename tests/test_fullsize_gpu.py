@@ -92,3 +92,29 @@ def test_cfg4_wideband_16_channel_zigbee():
     assert got <= sent
     _check_order(a)
     assert np.all(ok["lqi"] >= 150)
+
+
+def test_cfg5_concurrent_wideband_scans_equal_separate_runs():
+    """cfg #5 on one GPU: the BTLE 40-channel and the Zigbee 16-channel scan share the device (one
+    stream each, segments of 2^24 input samples submitted alternately); each yields exactly what it
+    yields alone, and what one un-sharded pass yields after overlap dedup."""
+    import torch
+    from snout_amd.sharded import ShardedScan, run_concurrent
+    tb, _ = synth.wideband_capture(0, 40 * (1 << 16), seed=3, sigma=0.0)
+    tz, _ = synth.wideband_capture(1, 16 * (1 << 17), seed=4, sigma=0.0, bins=range(0, 16, 2), max_len=100)
+    xb, xz = _tiled(tb, 26), _tiled(tz, 30)                    # 6.8e7 and 6.3e7 input samples
+    nb, nz = xb.numel() // 2, xz.numel() // 2
+    srcb = lambda a, b: xb[2 * a:2 * b]
+    srcz = lambda a, b: xz[2 * a:2 * b]
+    sb = ShardedScan(0, n_channels=40, seg_len=1 << 24)
+    sz = ShardedScan(1, n_channels=16, seg_len=1 << 24)
+    try:
+        alone_b = sb.run(nb, srcb)
+        alone_z = sz.run(nz, srcz)
+        both_b, both_z = run_concurrent([sb, sz], [nb, nz], [srcb, srcz])
+    finally:
+        sb.close(); sz.close()
+    assert np.array_equal(alone_b, both_b) and np.array_equal(alone_z, both_z)
+    assert len(both_b) > 5000 and len(both_z) > 1000
+    assert int(both_b["crc_ok"].sum()) >= 0.99 * len(both_b)
+    torch.cuda.synchronize()
