@@ -100,3 +100,18 @@ def test_rftap_datagrams_through_scan():
         assert m.datagram[:4] == b"RFta" and m.datagram[16:] == m.mpdu
         assert struct.unpack("<HHI", m.datagram[4:12]) == (4, 0x81, 195)
         assert m.channel == 15 and abs(m.qual - m.lqi / 255.0) < 1e-9
+
+
+@pytest.mark.parametrize("core,warmup", [(1024, 64), (1024, 960), (2048, 256), (8192, 512),
+                                          (4096, 2048), (16384, 4096)])
+def test_lane_shapes_match_oracle(oracle, core, warmup):
+    """Every (core, warm-up) shape the ABI accepts: candidate tile, stitch and tail tile move with them."""
+    n = (1 << 18) + 4321
+    x, truth = synth.zigbee_capture(n, seed=core + warmup, mean_gap=5000.0, cfo_max_hz=30e3)
+    with _rx(zb_core=core, zb_warmup=warmup) as rx:
+        got = rx.process(x, first_sample_index=99)
+    want = oracle.zigbee_segment(x, channel=11, core=core, warmup=warmup, first_sample_index=99)
+    _same_packets(got, want)
+    if warmup >= 256:       # a 64-sample warm-up is accepted but too short for the timing loop to lock
+        good = {bytes(p["bytes"][:p["len"]]) for p in got if p["crc_ok"]}
+        assert sum(t.payload in good for t in truth) >= len(truth) - 1
