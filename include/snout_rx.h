@@ -66,8 +66,8 @@ typedef struct snout_rx_cfg {
     uint32_t crc_init;        /* BTLE `-k` (btle.py:67); 0 -> 0x555555                           */
     uint32_t chip_threshold;  /* packet_sink(threshold) (top_block.py:67); 0 -> 10               */
     uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 -> 4096           */
-    uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 512 
-                                 (core and warm-up must be multiples of 64, warm-up < core)       */
+    uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 512;
+                                 multiples of 64, warm-up < core; the timing loop needs >= 256      */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
     uint32_t reserved[4];     /* [0] bit 0: wideband BTLE keeps channel IQ in HBM (unfused; needed for

@@ -142,10 +142,12 @@ struct ZbCtx {
              uint32_t warmup);
     void destroy();
     int reserve(uint64_t n_channel_samples);
-    int launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st);
-    // discriminator + lanes + ordered compaction into s.d_out / s.d_totals (no host sync)
-    int enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
-                ResultSlot& s, bool time_front);
+    int launch_sinks(uint64_t first_index, hipStream_t st);
+    // front end (discriminator, carry-in, lanes) and tail (stitch, sinks, ordered compaction into
+    // s.d_out / s.d_totals); no host sync
+    int enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
+                      bool time_front);
+    int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s, bool time_front);
     bool check_overflow(const ResultSlot& s);
     int soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out);
 };

@@ -96,6 +96,7 @@ struct snout_rx {
     int device = 0;
     bool wide = false;
     BtleCtx btle, btle2;      // two work sets: the tail of segment i overlaps the front end of i+1
+    ZbCtx zb2;                // (second Zigbee work set; the first is `zb`)
     hipStream_t tail_stream = nullptr;
     ZbCtx zb;
     PfbCtx pfb;
@@ -118,6 +119,7 @@ struct snout_rx {
 };
 
 static BtleCtx& btle_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->btle2 : h->btle; }
+static ZbCtx& zb_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->zb2 : h->zb; }
 
 // Enqueue every kernel of one segment, results into slot s.  No host synchronisation.
 // BTLE: the front end (demod+correlate, or channelizer+correlate) runs on the caller's stream `st`;
@@ -128,8 +130,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     const float* ch_iq = s.iq;
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
     SNOUT_HIP(hipEventRecord(s.ev_t0, st));
-    if (h->cfg.proto == SNOUT_PROTO_BTLE)     // the tail that last used this work set must be done
-        SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));
+    SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));   // the tail that last used this work set must be done
     const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.reserved[0] & 1u);
     if (h->wide) {
         n_ch = h->pfb.n_out_for(s.n_in);
@@ -157,12 +158,16 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], h->tail_stream));
         return 0;
     } else {
-        ZbCtx& z = h->zb;
+        ZbCtx& z = zb_of(h, s);
         if (int rc = z.reserve(n_ch)) return rc;
-        if (int rc = z.enqueue(ch_iq, n_ch, ch_stride, s.first_index, st, s, !h->wide)) return rc;
+        if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_front, st));
+        SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, s.ev_front, 0));
+        if (int rc = z.enqueue_tail(n_ch, s.first_index, h->tail_stream, s, !h->wide)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_compute, h->tail_stream));
+        SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], h->tail_stream));
+        return 0;
     }
-    SNOUT_HIP(hipEventRecord(s.ev_compute, st));
-    return 0;
 }
 
 // Totals (and `spec` records, speculatively) -> pinned host memory on the copy stream.
@@ -189,7 +194,7 @@ static int finish_slot(snout_rx* h, ResultSlot& s)
     for (int attempt = 0; attempt < 12; attempt++) {
         SNOUT_HIP(hipEventSynchronize(s.ev_copy));
         const bool over = h->cfg.proto == SNOUT_PROTO_BTLE ? btle_of(h, s).check_overflow(s)
-                                                           : h->zb.check_overflow(s);
+                                                           : zb_of(h, s).check_overflow(s);
         if (!over) { s.n_pkts = s.h_totals[1]; return SNOUT_OK; }
         // other segments in flight share this slot's work set every second submit: let them finish
         // (their results are already on their way to their own slots) before reusing it
@@ -284,6 +289,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (c.channel < 11 || c.channel > 26) { set_last_error("Zigbee channel %u", c.channel); goto fail; }
         uint16_t ch = (uint16_t)c.channel;
         rc = h->zb.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
+        if (!rc) rc = h->zb2.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (rc) goto fail;
     } else if ((c.proto == SNOUT_PROTO_BTLE && c.n_channels == 40) ||
                (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 16)) {
@@ -300,6 +306,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits)
                                          : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle2.init(M, chs, c.access_addr, c.crc_init, c.max_hits);
+        if (!rc && c.proto == SNOUT_PROTO_ZIGBEE) rc = h->zb2.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (rc) goto fail;
     } else {
         set_last_error("configuration proto=%u n_channels=%u not supported (BTLE: 1 or 40, "
@@ -346,6 +353,7 @@ void snout_rx_destroy(snout_rx* h)
     h->btle2.destroy();
     if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
     h->zb.destroy();
+    h->zb2.destroy();
     h->pfb.destroy();
     h->d_iq.release();
     for (auto& s : h->slots) s.destroy();
@@ -601,7 +609,7 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
     if (h->cfg.proto == SNOUT_PROTO_ZIGBEE && stage >= SNOUT_STAGE_ZB_DISCRIM &&
         stage <= SNOUT_STAGE_ZB_CHIPS) {
         if (h->last_nch < 9) return SNOUT_EINVAL;
-        return h->zb.soft(stage, channel_slot, h->last_nch, out, cap, n_out);
+        return (h->last ? zb_of(h, *h->last) : h->zb).soft(stage, channel_slot, h->last_nch, out, cap, n_out);
     }
     set_last_error("stage %u not available for this configuration", stage);
     return SNOUT_EINVAL;

@@ -722,6 +722,8 @@ __global__ __launch_bounds__(256) void zb_walk(
     uint32_t core, uint32_t warmup, uint32_t th, const uint16_t* __restrict__ slot_channel,
     uint64_t first_index, snout_pkt* __restrict__ stage, uint32_t K, uint32_t* __restrict__ lane_cnt)
 {
+    // a few latency-bound waves that run beside the next segment's front end: issue them first
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= total_lanes) return;
     const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
@@ -1020,8 +1022,8 @@ int ZbCtx::reserve(uint64_t n)
     return 0;
 }
 
-// a5-a7 on the discriminator tiles: lanes -> stitched chip streams -> sinks -> per-lane records.
-int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st)
+// a7 and the glue before it: stitched chip streams -> sinks -> per-lane records (after zb_mm).
+int ZbCtx::launch_sinks(uint64_t first_index, hipStream_t st)
 {
     uint32_t* first_owned = d_lane_u32.as<uint32_t>();
     uint32_t* owned = first_owned + total_lanes;
@@ -1029,10 +1031,6 @@ int ZbCtx::launch_lanes(uint64_t n, uint64_t first_index, hipStream_t st)
     uint32_t* tsum = offs + total_lanes;
     uint32_t* slot_total = tsum + (uint64_t)tiles_per_slot * n_slots;
     SNOUT_HIP(hipMemsetAsync(d_stream.p, 0, stream_words * n_slots * 8u, st));
-    hipLaunchKernelGGL(zb_mm<false>, dim3(n_waves), dim3(64), 0, st, d_dT.as<float>(), n, nt, lanes_per_slot,
-                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
-                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
-                       (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
     hipLaunchKernelGGL(zb_stitch, dim3(tiles_per_slot, n_slots), dim3(256), 0, st,
                        d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(), lanes_per_slot, core, warmup,
                        tiles_per_slot, first_owned, owned, tsum);
@@ -1107,21 +1105,13 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     return SNOUT_EINVAL;
 }
 
+// Front end (a4-a6) on the caller's stream: discriminator tiles, IIR carry-in, lanes.
 // iq: [n_slots][iq_stride] complex samples at 4 Msps per channel, device memory.  No host sync.
-// totals (u32): [0] lanes  [1] packets  [2] lanes that held more than pkts_per_lane frames
-int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t first_index, hipStream_t st,
-                   ResultSlot& s, bool time_front)
+int ZbCtx::enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
+                         ResultSlot& s, bool time_front)
 {
-    if (int rc = s.d_out.ensure((uint64_t)max_out * sizeof(snout_pkt))) return rc;
-    uint32_t* tot = s.d_totals.as<uint32_t>();
-    uint32_t* sums = tot + 16;
-    uint32_t* over = tot + 16 + kMaxTiles;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
-    if (n < 9u) {           // no interpolator window fits: nothing to launch
-        SNOUT_HIP(hipMemsetAsync(tot, 0, 16, st));
-        if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
-        return 0;
-    }
+    if (n < 9u) return 0;   // no interpolator window fits: nothing to launch
     hipLaunchKernelGGL(zb_discrim, dim3(n_waves * (core / 64u)), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
                        lanes_per_slot, total_lanes, core, core / 64u, nsb, d_atan.as<float>(),
                        d_iirw.as<double>(), d_dT.as<float>(), d_S.as<double>());
@@ -1130,7 +1120,29 @@ int ZbCtx::enqueue(const float* d_iq, uint64_t n, uint64_t iq_stride, uint64_t f
     hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
                        lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
                        d_lp_in.as<double>());
-    if (int rc = launch_lanes(n, first_index, st)) return rc;
+    hipLaunchKernelGGL(zb_mm<false>, dim3(n_waves), dim3(64), 0, st, d_dT.as<float>(), n, nt, lanes_per_slot,
+                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
+                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
+                       (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
+    SNOUT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Tail (stitch, a7, ordered compaction into s.d_out / s.d_totals) on the handle's tail stream, so
+// that it overlaps the next segment's front end (which uses the other work set).  No host sync.
+// totals (u32): [0] lanes  [1] packets  [2] lanes that held more than pkts_per_lane frames
+int ZbCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s, bool time_front)
+{
+    if (int rc = s.d_out.ensure((uint64_t)max_out * sizeof(snout_pkt))) return rc;
+    uint32_t* tot = s.d_totals.as<uint32_t>();
+    uint32_t* sums = tot + 16;
+    uint32_t* over = tot + 16 + kMaxTiles;
+    if (n < 9u) {
+        SNOUT_HIP(hipMemsetAsync(tot, 0, 16, st));
+        if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
+        return 0;
+    }
+    if (int rc = launch_sinks(first_index, st)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
     launch_tile_reduce(d_lane_cnt.as<uint32_t>(), nullptr, total_lanes, total_lanes, pkts_per_lane,
