@@ -191,15 +191,39 @@ __global__ __launch_bounds__(256) void btle_corr_planes(
     const uint32_t it0 = chunk * (uint32_t)kChunkIters;
     uint32_t cnt = 0;
     uint32_t* list = chunk_hits + (size_t)wid * cap;
-    // iterate over the 64 iterations of the chunk; every lane tests symbol `lane` of each
-    for (uint32_t r = 0; r < (uint32_t)kChunkIters; r++) {
+    // The chunk's 64 x 4 plane words in one coalesced load: lane l holds iteration it0 + l, the
+    // iteration before it comes from lane l-1 (lane 0: one uniform load).
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(pl + ((size_t)it0 + lane) * 4u);
+    const ulonglong2 wa = src[0], wb = src[1];
+    const uint64_t w[4] = {wa.x, wa.y, wb.x, wb.y};
+    uint64_t pv[4];
+    uint32_t cand = 0;                      // phases of this lane's iteration that may hold a match
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t up = __shfl_up(w[j], 1);
+        pv[j] = lane ? up : (it0 > 0 ? pl[(size_t)(it0 - 1u) * 4u + j] : 0ull);
+        // Bit-parallel pre-filter over the 64 symbol positions of the word: the newest 16 symbols of
+        // the 32-symbol window must equal the top half of the access address.  T_i has, at bit l,
+        // the symbol that window bit i of position l looks at.
+        uint64_t m = ~0ull;
+#pragma unroll
+        for (uint32_t i = 16; i < 32u; i++) {
+            const uint64_t t = i == 31u ? w[j] : ((pv[j] >> (33u + i)) | (w[j] << (31u - i)));
+            m &= ((aa >> i) & 1u) ? t : ~t;
+        }
+        cand |= (m != 0ull ? 1u : 0u) << j;
+    }
+    // exact test (every lane one symbol position) only for the few iterations that passed
+    uint64_t rows = __ballot(cand != 0u);
+    while (rows) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(rows);
+        rows &= rows - 1ull;
         const uint32_t it = it0 + r;
         bool hit[4];
         bool any = false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint64_t cur = pl[(size_t)it * 4u + j];
-            const uint64_t prv = it > 0 ? pl[(size_t)(it - 1) * 4u + j] : 0ull;
+            const uint64_t cur = __shfl(w[j], (int)r), prv = __shfl(pv[j], (int)r);
             const uint64_t n = (uint64_t)it * kIterSamples + 4u * lane + (uint32_t)j;
             hit[j] = (aa_window(prv, cur, lane) == aa) && n >= 124u && n < nb;
             any |= hit[j];
