@@ -1002,6 +1002,10 @@ int ZbCtx::reserve(uint64_t n)
     nt = (core + warmup) / 64u + 1u;
     tiles_per_slot = cdiv(lanes_per_slot, kScanTile);
     stream_words = n / 64u + 4u;                    // at most one chip per sample
+    if (n >= (1ull << 31)) {    // chip and lane-relative indices are 32-bit
+        set_last_error("Zigbee segment of %llu channel samples: at most 2^31 - 1 per call", (unsigned long long)n);
+        return SNOUT_ERANGE;
+    }
     if (cdiv(total_lanes, 1024) > kMaxTiles) { set_last_error("too many lanes"); return SNOUT_ERANGE; }
     if ((uint64_t)n_waves * nt > 0x7FFFFFFFull) { set_last_error("too many lane tiles"); return SNOUT_ERANGE; }
     if (int rc = d_dT.ensure((uint64_t)n_waves * (core / 64u) * 4096u * 4u)) return rc;
