@@ -71,13 +71,17 @@ def btle():
 
 @btle.command("scan")
 @_scan_options
-def btle_scan(channels, packets, timeout, filename, iq, synthetic, seconds):
+@click.option("--summary", is_flag=True, help="print the device table at the end (snout/util/btle.py:202-240)")
+def btle_scan(channels, packets, timeout, filename, iq, synthetic, seconds, summary):
     chs = parse_channels(channels or DEFAULTS["btle"]["default"], "btle")
     scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds),
                     timeout=timeout, packet_threshold=packets, filename=filename)
     scan.events.on("btle.packet-received",
                    lambda message: click.echo(message.raw.decode().rstrip("\n")))
     msgs = scan.run()
+    if summary:
+        from .devices import DeviceTable
+        click.echo(DeviceTable().extend(msgs).render())
     click.echo(f"{len(msgs)} packets, {len({m.sender for m in msgs})} devices", err=True)
 
 
@@ -93,8 +97,16 @@ def zigbee_scan(channels, packets, timeout, filename, iq, synthetic, seconds, ud
     chs = parse_channels(channels or DEFAULTS["zigbee"]["default"], "zigbee")
     scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds),
                       timeout=timeout, packet_threshold=packets, udp=udp)
-    scan.events.on("zigbee.packet-received", lambda message: click.echo(
-        f"{message.timestamp:.6f} Ch{message.channel} LQI{message.lqi} {message.mpdu.hex()}"))
+    def show(message):
+        from .formats import parse_mhr
+        try:
+            h = parse_mhr(message.mpdu)
+            hdr = f"{h['frame_type_name']} seq{h['seq']}"
+        except ValueError:
+            hdr = "short"
+        click.echo(f"{message.timestamp:.6f} Ch{message.channel} LQI{message.lqi} {hdr} {message.mpdu.hex()}")
+
+    scan.events.on("zigbee.packet-received", show)
     msgs = scan.run()
     if filename:
         from .formats import write_pcap
