@@ -129,11 +129,12 @@ struct ZbCtx {
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
     uint32_t n_waves = 0, nt = 0, tiles_per_slot = 0;   // waves of 64 lanes, 64-sample tiles per lane
     uint64_t stream_words = 0;                          // u64 words of one channel's chip stream
+    uint64_t d_stride = 0;                              // floats per channel row of the discriminator output
     bool overflow = false;
     DevBuf d_atan, d_mmse, d_slot_channel, d_stage, d_lane_cnt, d_soft;
-    // discriminator tiles, tile records, per-lane stitch inputs, candidate keys,
+    // discriminator output rows, tile records, per-lane stitch inputs, candidate keys,
     // first_owned|owned|offs|tsum|slot_total, chip streams
-    DevBuf d_dT, d_TR, d_lane_out, d_cand, d_lane_u32, d_stream;
+    DevBuf d_d, d_TR, d_lane_out, d_cand, d_lane_u32, d_stream;
     DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
     double d64 = 0, dcore = 0, dfirst = 0;
     uint64_t nsb = 0;

@@ -13,9 +13,9 @@
 // lanes are stitched into one chip stream per channel and the packet sink runs on that bit stream
 // (oracle_zigbee.c states the same rules).  One wave = 64 lanes.
 //
-//   zb_discrim  HBM-bound; writes the discriminator output as (wave, tile) blocks transposed so
-//               that thread = lane reads its own samples with coalesced loads
-//   zb_mm       IIR + M&M per lane, chips + window advances as 64-bit words per 64-sample tile
+//   zb_discrim  streaming: discriminator output d[slot][t] and the IIR sub-block sums S_j
+//   zb_mm       IIR + M&M per lane (thread = lane reads its own row of d in 16-byte pieces), chips +
+//               window advances as 64-bit words per 64-sample tile
 //   zb_stitch / zb_offsets / zb_scatter   first owned chip per lane, stream offsets, bit stream
 //   zb_walk     the sink FSM per lane on the bit stream (per-chip search, 32-chip symbol steps)
 #include "common.h"
@@ -57,113 +57,70 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
 
 constexpr uint32_t kTrFields = 9;  // tile record: cw lo/hi, d_lo lo/hi, d_hi lo/hi, nc, cstart, ii_start
 
-// Tile (wave w, tile t) of the transposed discriminator array: element (col, row) = sample 64 t + col
-// of lane 64 w + row, so the 64 lanes of a wave read one coalesced 256-B line per sample.
-__device__ __forceinline__ uint64_t dt_index(uint32_t w, uint32_t nt, uint32_t t, uint32_t col, uint32_t row)
-{
-    return (((uint64_t)w * nt + t) * 64u + col) * 64u + row;
-}
 __device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t, uint32_t field, uint32_t row)
 {
     return (((uint64_t)w * nt + t) * kTrFields + field) * 64u + row;
 }
 
-// One block per (wave of 64 lanes, 64-sample tile of their cores): wave v of the block computes rows
-// 16v..16v+15 (row = lane, 64 consecutive samples each, coalesced 512-B reads), the block
-// transposes through LDS and writes the tile as 64 lines of 64 lanes (see dt_index).  Only core
-// tiles are stored: a lane's warm-up samples are the last core tiles of the lane before it and
-// zb_mm reads them from there.  The block also emits S_j, the zero-state response of the
-// single-pole IIR to each row's 64 samples (double, fixed order), from which zb_iir_fold /
-// zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the oracle).
+// Streaming: a wave turns 256 consecutive samples of one channel into discriminator values
+// d[slot][t] (8 B read, 4 B written per sample, 16-byte stores; x[t-1] by whole-wave DPP shift, the
+// first lane's from its own load); rows beyond n up to the padded stride are written as zeros so
+// that every lane of zb_mm may read whole tiles.  Each 64-sample sub-block also yields S_j, the
+// zero-state response of the single-pole IIR to its samples (double, fixed order), from which
+// zb_iir_fold / zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the
+// oracle): four threads per sub-block sum 16 terms each in sequence, S = (P0 + P1) + (P2 + P3).
 __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq, uint64_t n,
-                                                  uint64_t iq_stride, uint32_t lanes_per_slot,
-                                                  uint32_t total_lanes, uint32_t core, uint32_t ntc,
-                                                  uint64_t nsb, const float* __restrict__ atan_tab,
+                                                  uint64_t iq_stride, uint64_t d_stride, uint64_t nsb,
+                                                  const float* __restrict__ atan_tab,
                                                   const double* __restrict__ iir_w,
-                                                  float* __restrict__ dT, double* __restrict__ S)
+                                                  float* __restrict__ d, double* __restrict__ S)
 {
     __shared__ float tab[257];
     __shared__ double wts[64];
-    __shared__ float tile[64 * 65];
+    __shared__ float ang_s[1024];
     for (uint32_t i = threadIdx.x; i < 257; i += 256) tab[i] = atan_tab[i];
     if (threadIdx.x < 64) wts[threadIdx.x] = iir_w[threadIdx.x];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: row math on the SALU
-    const uint32_t w = blockIdx.x / ntc, t = blockIdx.x % ntc;
-    // (slot, lane-in-slot) of the wave's first row by one division, then stepped row by row.
-    // All 16 row loads are issued before any arithmetic (the kernel is bound by bytes in flight);
-    // out-of-range rows read a clamped address and are zeroed afterwards.  x[t-1] is the
-    // neighbouring lane's sample (whole-wave DPP shift); lane 0 takes it from a scalar load.
-    uint32_t slot = (w * 64u + v * 16u) / lanes_per_slot, li = (w * 64u + v * 16u) % lanes_per_slot;
-    float2 xa[16], x0[16];
-    uint32_t okm = 0;                                       // bit k: row k exists
+    const uint32_t slot = blockIdx.y;
+    const float2* x = iq + (uint64_t)slot * iq_stride;
+    const uint64_t t0 = (uint64_t)blockIdx.x * 1024u + 4u * threadIdx.x;      // this thread's 4 samples
+    float ang[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (t0 < n) {
+        float2 xs[5];
+        xs[0] = t0 ? x[t0 - 1u] : make_float2(0.0f, 0.0f);
+        if (t0 + 3u < n) {
+            const float4 a = *reinterpret_cast<const float4*>(&x[t0]);
+            const float4 b = *reinterpret_cast<const float4*>(&x[t0 + 2u]);
+            xs[1] = make_float2(a.x, a.y); xs[2] = make_float2(a.z, a.w);
+            xs[3] = make_float2(b.x, b.y); xs[4] = make_float2(b.z, b.w);
+        } else {
 #pragma unroll
-    for (uint32_t k = 0; k < 16u; k++) {
-        const uint32_t g = w * 64u + v * 16u + k;
-        const bool ok = g < total_lanes;
-        const uint64_t a0 = ok ? (uint64_t)li * core + 64ull * t : 0ull;     // first sample of the row
-        const float2* x = iq + (uint64_t)(ok ? slot : 0u) * iq_stride;
-        const uint64_t ta = a0 + lane;
-        xa[k] = x[ta < n ? ta : (n - 1u)];
-        x0[k] = (a0 > 0ull && a0 <= n) ? x[a0 - 1u] : make_float2(0.0f, 0.0f);   // uniform address
-        okm |= (ok ? 1u : 0u) << k;
-        if (++li == lanes_per_slot) { li = 0u; slot++; }
-    }
-    {
-        uint32_t li2 = (w * 64u + v * 16u) % lanes_per_slot;
+            for (uint32_t k = 0; k < 4u; k++) xs[1 + k] = t0 + k < n ? x[t0 + k] : make_float2(0.0f, 0.0f);
+        }
 #pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) {
-            const uint64_t ta = (uint64_t)li2 * core + 64ull * t + lane;
-            const float2 a = xa[k];
-            float2 p;
-            p.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x0[k].x), __builtin_bit_cast(int, a.x), 0x138, 0xf, 0xf, false));
-            p.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x0[k].y), __builtin_bit_cast(int, a.y), 0x138, 0xf, 0xf, false));
+        for (uint32_t k = 0; k < 4u; k++) {
+            const float2 a = xs[k + 1], p = xs[k];
             const float re = a.x * p.x + a.y * p.y;          // contraction is off: products round first
             const float im = a.y * p.x - a.x * p.y;
-            float ang = fast_atan2f_tab(im, re, tab);
-            if (!(fabsf(ang) <= 4.0f)) ang = 0.0f;          // non-finite input: defined as 0 (as the oracle)
-            if (!((okm >> k) & 1u) || ta >= n) ang = 0.0f;
-            tile[(v * 16u + k) * 65u + lane] = ang;
-            if (++li2 == lanes_per_slot) li2 = 0u;
+            float v = fast_atan2f_tab(im, re, tab);
+            if (!(fabsf(v) <= 4.0f)) v = 0.0f;              // non-finite input: defined as 0 (as the oracle)
+            ang[k] = t0 + k < n ? v : 0.0f;
         }
     }
+    if (t0 < d_stride) *reinterpret_cast<float4*>(&d[(uint64_t)slot * d_stride + t0]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+    *reinterpret_cast<float4*>(&ang_s[4u * threadIdx.x]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
     __syncthreads();
-    // S_j of the wave's 16 rows (oracle order): four threads per row sum 16 terms each in sequence,
-    // S = (P0 + P1) + (P2 + P3)
-    {
-        const uint32_t r = v * 16u + (lane & 15u), part = lane >> 4;
+    if (threadIdx.x < 64u) {
+        const uint32_t sb = threadIdx.x >> 2, part = threadIdx.x & 3u;      // 16 sub-blocks x 4 parts
         double acc = 0.0;
 #pragma unroll
         for (uint32_t k = 0; k < 16u; k++)
-            acc = acc + wts[63u - (16u * part + k)] * (double)tile[r * 65u + 16u * part + k];
-        acc = acc + __shfl_down(acc, 16);
-        acc = acc + __shfl_down(acc, 32);
-        const uint32_t g = w * 64u + r;
-        if (lane < 16u && g < total_lanes) {
-            const uint64_t j = ((uint64_t)(g % lanes_per_slot) * core + 64ull * t) >> 6;
-            if (j < nsb) S[(uint64_t)(g / lanes_per_slot) * nsb + j] = acc;
-        }
+            acc = acc + wts[63u - (16u * part + k)] * (double)ang_s[64u * sb + 16u * part + k];
+        acc = acc + __shfl_down(acc, 1);                    // P0 + P1 (part 0), P2 + P3 (part 2)
+        acc = acc + __shfl_down(acc, 2);                    // (P0 + P1) + (P2 + P3)
+        const uint64_t j = (uint64_t)blockIdx.x * 16u + sb;
+        if (part == 0u && j < nsb) S[(uint64_t)slot * nsb + j] = acc;
     }
-    float* out = dT + ((uint64_t)w * ntc + t) * 4096u;
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; k++) {
-        const uint32_t idx = k * 256u + threadIdx.x;        // = col * 64 + row
-        out[idx] = tile[(idx & 63u) * 65u + (idx >> 6)];
-    }
-}
-
-// Test tap: channel-ordered discriminator output of one slot, gathered from the core tiles.
-__global__ __launch_bounds__(256) void zb_gather_d(const float* __restrict__ dT, uint64_t n, uint32_t slot,
-                                                   uint32_t lanes_per_slot, uint32_t core, uint32_t ntc,
-                                                   float* __restrict__ out, uint64_t cap)
-{
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= n || t >= cap) return;
-    const uint32_t li = (uint32_t)(t / core);
-    const uint32_t rel = (uint32_t)(t - (uint64_t)li * core);
-    const uint32_t g = slot * lanes_per_slot + li;
-    out[t] = dT[dt_index(g >> 6, ntc, rel >> 6, rel & 63u, g & 63u)];
 }
 
 // Lane block i = [s0_i, s0_{i+1}): fold its sub-block sums, L = D64 L + S_j (one thread per lane).
@@ -225,8 +182,9 @@ struct ZbLaneOut {
 // sinks run on bits (zb_walk).
 template <bool TAP>
 __global__ __launch_bounds__(64) void zb_mm(
-    const float* __restrict__ dT, uint64_t n, uint32_t nt, uint32_t lanes_per_slot, uint32_t total_lanes,
-    uint32_t core, uint32_t warmup, const float* __restrict__ mmse, const double* __restrict__ lp_in,
+    const float* __restrict__ d, uint64_t d_stride, uint64_t n, uint32_t nt, uint32_t lanes_per_slot,
+    uint32_t total_lanes, uint32_t core, uint32_t warmup, const float* __restrict__ mmse,
+    const double* __restrict__ lp_in,
     uint32_t* __restrict__ TR, ZbLaneOut* __restrict__ lane_out, uint32_t* __restrict__ cand_keys,
     float* __restrict__ soft_z, float* __restrict__ soft_chips, uint32_t soft_lane, uint32_t soft_cap,
     uint32_t* __restrict__ soft_n)
@@ -262,28 +220,19 @@ __global__ __launch_bounds__(64) void zb_mm(
 #pragma unroll
     for (int k = 0; k < 8; k++) zl[k] = 0.0f;
 
-    // Where tile t of this lane lives: warm-up tiles are the last core tiles of the lane before,
-    // the tail tile is the first core tile of the lane after (only core tiles are stored).
-    const uint32_t ntc = core >> 6;
-    const uint32_t g_next = (active && li + 1u < lanes_per_slot) ? g + 1u : g;     // tail unused if no next lane
-    auto tile_ptr = [&](uint32_t t) -> const float* {
-        uint32_t sg = g, tc = 0;
-        if (li == 0u || !active) {
-            if (t < ntc) tc = t; else if (t == ntc) sg = g_next;
-        } else if (t < tb) {
-            sg = g - 1u; tc = ntc - tb + t;
-        } else if (t < tb + ntc) {
-            tc = t - tb;
-        } else {
-            sg = g_next;
-        }
-        return dT + dt_index(sg >> 6, ntc, tc, 0u, sg & 63u);
-    };
+    // The lane's samples are a row of d: tile t = 64 floats at d_row + 64 t, fetched as 16-byte
+    // pieces one tile ahead.  Every lane reads its own row (the 64 lanes of a load touch 64 lines,
+    // each line is used by eight consecutive loads) -- the texture path has room for that beside
+    // ~2 600 VALU instructions per tile, and nothing has to be transposed anywhere.
+    const float* d_row = d + (uint64_t)(active ? g / lanes_per_slot : 0u) * d_stride + (active ? s0 : 0ull);
     float pre[64];
     {
-        const float* tp = tile_ptr(0u);
+        const float4* tp = reinterpret_cast<const float4*>(d_row);
 #pragma unroll
-        for (uint32_t col = 0; col < 64u; col++) pre[col] = tp[col * 64u];
+        for (uint32_t c4 = 0; c4 < 16u; c4++) {
+            const float4 v4 = tp[c4];
+            pre[4 * c4] = v4.x; pre[4 * c4 + 1] = v4.y; pre[4 * c4 + 2] = v4.z; pre[4 * c4 + 3] = v4.w;
+        }
     }
 
     for (uint32_t tile = 0; tile < nt; tile++) {
@@ -319,9 +268,12 @@ __global__ __launch_bounds__(64) void zb_mm(
             }
             // next tile's samples: in flight during the second half's M&M steps
             if (hb == 32u && tile + 1u < nt) {
-                const float* tp = tile_ptr(tile + 1u);
+                const float4* tp = reinterpret_cast<const float4*>(d_row + 64u * (tile + 1u));
 #pragma unroll
-                for (uint32_t col = 0; col < 64u; col++) pre[col] = tp[col * 64u];
+                for (uint32_t c4 = 0; c4 < 16u; c4++) {
+                    const float4 v4 = tp[c4];
+                    pre[4 * c4] = v4.x; pre[4 * c4 + 1] = v4.y; pre[4 * c4 + 2] = v4.z; pre[4 * c4 + 3] = v4.w;
+                }
             }
             const uint32_t staged = r0 + (nz < hb + 32u ? nz : hb + 32u);
             const uint32_t hi = staged < avail ? staged : avail;
@@ -989,7 +941,7 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
 void ZbCtx::destroy()
 {
     d_atan.release(); d_mmse.release(); d_slot_channel.release();
-    d_dT.release(); d_TR.release(); d_lane_out.release(); d_cand.release(); d_lane_u32.release();
+    d_d.release(); d_TR.release(); d_lane_out.release(); d_cand.release(); d_lane_u32.release();
     d_stream.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
     d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
 }
@@ -1008,7 +960,9 @@ int ZbCtx::reserve(uint64_t n)
     }
     if (cdiv(total_lanes, 1024) > kMaxTiles) { set_last_error("too many lanes"); return SNOUT_ERANGE; }
     if ((uint64_t)n_waves * nt > 0x7FFFFFFFull) { set_last_error("too many lane tiles"); return SNOUT_ERANGE; }
-    if (int rc = d_dT.ensure((uint64_t)n_waves * (core / 64u) * 4096u * 4u)) return rc;
+    d_stride = (uint64_t)(lanes_per_slot + 1u) * core + 1024u;   // whole tiles past the last core, 16-B rows
+    d_stride = (d_stride + 1023u) & ~1023ull;
+    if (int rc = d_d.ensure(d_stride * n_slots * 4u)) return rc;
     if (int rc = d_TR.ensure((uint64_t)n_waves * nt * 9u * 64u * 4u)) return rc;
     if (int rc = d_lane_out.ensure((uint64_t)total_lanes * 32u)) return rc;
     if (int rc = d_cand.ensure((uint64_t)total_lanes * 12u * 4u)) return rc;
@@ -1064,14 +1018,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
         // `lane` selects the channel slot here
         if (lane >= n_slots) return SNOUT_EINVAL;
         const uint64_t m = n < cap ? n : cap;
-        DevBuf tmp;
-        if (int rc = tmp.ensure((m ? m : 1) * 4u)) return rc;
-        if (m) {
-            hipLaunchKernelGGL(zb_gather_d, dim3(cdiv(m, 256)), dim3(256), 0, nullptr, d_dT.as<float>(), n, lane,
-                               lanes_per_slot, core, core / 64u, tmp.as<float>(), m);
-            SNOUT_HIP(hipMemcpy(out, tmp.p, m * 4u, hipMemcpyDeviceToHost));
-        }
-        tmp.release();
+        if (m) SNOUT_HIP(hipMemcpy(out, d_d.as<float>() + (uint64_t)lane * d_stride, m * 4u, hipMemcpyDeviceToHost));
         *n_out = n;
         return n > cap ? SNOUT_EOVERFLOW : 0;
     }
@@ -1080,7 +1027,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     float* sc = d_soft.as<float>() + kSoftCap;
     uint32_t* sn = (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap);
     // re-run the lanes with the tap on (rewrites identical tile records)
-    hipLaunchKernelGGL(zb_mm<true>, dim3(n_waves), dim3(64), 0, nullptr, d_dT.as<float>(), n, nt, lanes_per_slot,
+    hipLaunchKernelGGL(zb_mm<true>, dim3(n_waves), dim3(64), 0, nullptr, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
                        sz, sc, lane, (uint32_t)kSoftCap, sn);
@@ -1116,15 +1063,15 @@ int ZbCtx::enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipS
 {
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
     if (n < 9u) return 0;   // no interpolator window fits: nothing to launch
-    hipLaunchKernelGGL(zb_discrim, dim3(n_waves * (core / 64u)), dim3(256), 0, st, (const float2*)d_iq, n, iq_stride,
-                       lanes_per_slot, total_lanes, core, core / 64u, nsb, d_atan.as<float>(),
-                       d_iirw.as<double>(), d_dT.as<float>(), d_S.as<double>());
+    hipLaunchKernelGGL(zb_discrim, dim3(cdiv(d_stride, 1024), n_slots), dim3(256), 0, st, (const float2*)d_iq, n,
+                       iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(),
+                       d_S.as<double>());
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
     hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
                        lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
                        d_lp_in.as<double>());
-    hipLaunchKernelGGL(zb_mm<false>, dim3(n_waves), dim3(64), 0, st, d_dT.as<float>(), n, nt, lanes_per_slot,
+    hipLaunchKernelGGL(zb_mm<false>, dim3(n_waves), dim3(64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
                        (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
