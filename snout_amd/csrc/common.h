@@ -108,6 +108,16 @@ void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fi
                         hipStream_t st);
 
 // Polyphase channelizer (pfb.hip): wideband cf32 -> [M][n_out] channel IQ at 2 fs/M.
+// Fused 802.15.4 mode of the M = 16 channelizer: where the discriminator rows and IIR sub-block sums go.
+struct PfbZbTarget {
+    float* d;
+    uint64_t d_stride;
+    double* S;
+    uint64_t nsb;
+    const float* atan_tab;
+    const double* iir_w;
+};
+
 struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
@@ -118,8 +128,9 @@ struct PfbCtx {
     void destroy();
     uint64_t n_out_for(uint64_t n) const;
     // planes16 != null (M = 40): fused BTLE mode, hard bits go straight into the bit planes
+    // zbt != null (M = 16): fused 802.15.4 mode, discriminator output goes straight to the Zigbee context
     int run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16 = nullptr,
-            uint64_t plane_stride = 0);
+            uint64_t plane_stride = 0, const PfbZbTarget* zbt = nullptr);
 };
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
@@ -146,8 +157,10 @@ struct ZbCtx {
     int launch_sinks(uint64_t first_index, hipStream_t st);
     // front end (discriminator, carry-in, lanes) and tail (stitch, sinks, ordered compaction into
     // s.d_out / s.d_totals); no host sync
+    // d_iq == nullptr: the fused channelizer has already written d and S (see pfb_target)
     int enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
                       bool time_front);
+    PfbZbTarget pfb_target() const;
     int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s, bool time_front);
     bool check_overflow(const ResultSlot& s);
     int soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out);

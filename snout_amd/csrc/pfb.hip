@@ -24,6 +24,7 @@
 // The FIR is NOT GEMM-shaped (a per-branch sliding correlation: a Toeplitz operand with 2 useful
 // columns), so MFMA does not apply; see DESIGN.md.
 #include "common.h"
+#include "zb_discrim.h"
 #include "pfb_tables.inc"
 
 namespace snout {
@@ -101,6 +102,17 @@ __device__ __forceinline__ void lds_barrier()
 #define SNOUT_PFB_WPE 4
 #endif
 
+// Where the fused M = 16 (802.15.4) epilogue writes: discriminator rows and IIR sub-block sums of
+// the Zigbee context, plus the tables its arithmetic needs.
+struct PfbZbOut {
+    float* d;
+    uint64_t d_stride;
+    double* S;
+    uint64_t nsb;
+    const float* atan_tab;
+    const double* iir_w;
+};
+
 template <int M> struct PfbGeom;
 template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320; };
 template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256; };
@@ -108,6 +120,13 @@ template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, N
 // One workgroup walks a contiguous range of tiles of T output times.  Consecutive tiles share
 // (MP - D) input samples: they stay in LDS (moved to the front through registers), only T D new
 // samples are fetched per tile, one tile ahead, into registers.
+//
+// FUSED (802.15.4, M = 16): the tile's outputs never leave LDS either: thread (channel, 8 output
+// times) applies the FM discriminator d[m] = fast_atan2f(y[m] conj y[m-1]) (zb_discrim.h) and stores
+// d and the IIR sub-block sums S_j straight into the Zigbee context (4 B instead of 8 B written
+// per channel sample, and no zb_discrim pass: 8 B read + 4 B written saved again).  y[m0 - 1]
+// comes from the previous tile through LDS, so the workgroup first computes the tile before its
+// range without emitting it.
 //
 // FUSED (BTLE, M = 40): instead of writing 16 B of channel IQ per input sample the tile keeps its
 // outputs in LDS and emits the BTLE hard bits  bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m])  of all 40
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
-    uint64_t plane_stride)
+    uint64_t plane_stride, PfbZbOut zb)
 {
     using G = PfbGeom<M>;
     constexpr int T = G::T, M1 = G::M1, M2 = G::M2, D = M / 2, P = 16, NT = G::NT;
@@ -134,10 +153,21 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     __shared__ float2 xs[SPAN];                    // input span of the current tile
     __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
     __shared__ float tw_s[2 * M + 10];
+    constexpr bool ZB = FUSED && M == 16;          // fused 802.15.4 discriminator epilogue
+    constexpr int DLROW = T + 1;                   // padded row of the tile's d values (S_j reads)
+    static_assert(!ZB || (M * DLROW <= 2 * SPAN && T == 128 && NT == 256), "d tile reuses the input span");
+    __shared__ float atan_s[ZB ? 257 : 1];
+    __shared__ double wts_s[ZB ? 64 : 1];
+    __shared__ float2 prevy[ZB ? M : 1];           // y[m0 - 1] of every channel
 
     const int t = threadIdx.x;
     for (int i = t; i < 2 * M; i += NT) tw_s[i] = twM[i];
     if (t < 10) tw_s[2 * M + t] = tw5g[t];
+    if constexpr (ZB) {
+        for (int i = t; i < 257; i += NT) atan_s[i] = zb.atan_tab[i];
+        if (t < 64) wts_s[t] = zb.iir_w[t];
+        if (t < M) prevy[t] = make_float2(0.0f, 0.0f);         // x[-1] = 0 for the very first tile
+    }
     // FIR role of this thread: (branch r, output parity e, group grp); taps live in registers
     const int r = t % M, e = (t / M) & 1, grp = t / (2 * M);
     float h[P];
@@ -148,8 +178,10 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     uint32_t t_end = t_begin + tiles_per_wg;
     if (t_end > n_tiles) t_end = n_tiles;
     if (t_begin >= t_end) return;
-    // fused: one more tile (if it exists) supplies the samples the last symbols are compared with
-    const uint32_t t_last = (FUSED && t_end < n_tiles) ? t_end + 1u : t_end;
+    // fused BTLE: one more tile (if it exists) supplies the samples the last symbols are compared with;
+    // fused 802.15.4: the tile before the range supplies y[m0 - 1]
+    const uint32_t t_last = (FUSED && M == 40 && t_end < n_tiles) ? t_end + 1u : t_end;
+    const uint32_t t_first = (ZB && t_begin > 0u) ? t_begin - 1u : t_begin;
 
     const float4* x4 = reinterpret_cast<const float4*>(x);
     auto load_pair = [&](uint64_t g) -> float4 {               // samples g, g+1 (g even), zero past n
@@ -161,7 +193,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     // first tile: the whole span; later tiles: the overlap comes from LDS (keep), the rest from pre
     float4 keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre[NPRE];
     {
-        const uint64_t in0 = (uint64_t)t_begin * NEW;            // even -> 16-byte aligned
+        const uint64_t in0 = (uint64_t)t_first * NEW;            // even -> 16-byte aligned
         if (t < OV4) keep = load_pair(in0 + 2ull * (uint64_t)t);
 #pragma unroll
         for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in0 + 2ull * (uint64_t)(OV4 + t + k * NT));
@@ -171,7 +203,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     uint32_t pend = 0;                             // its 15 decided bits
     bool have_prev = false;
 
-    for (uint32_t tile = t_begin; tile < t_last; tile++) {
+    for (uint32_t tile = t_first; tile < t_last; tile++) {
         const uint64_t m0 = (uint64_t)tile * T;
         // ---- 1. stage: overlap to the front, new samples behind it
         if (t < OV4) reinterpret_cast<float4*>(xs)[t] = keep;
@@ -259,7 +291,49 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             }
         }
 
-        if constexpr (FUSED) {
+        if constexpr (ZB) {
+            lds_barrier();
+            // ---- 4z. discriminator.  Thread <-> (channel k, output times 8 seg .. 8 seg + 7); channel
+            //      k = k1 + M1 k2 sits in slot M2 k1 + k2 of every row.
+            float* dl = reinterpret_cast<float*>(xs);                 // [k][DLROW]: the span is dead here
+            const int k = t & (M - 1), seg = t / M;
+            const float2* col = &us[M2 * (k % M1) + (k / M1)];
+            float2 p = seg ? col[(8 * seg - 1) * ROW] : prevy[k];
+            float dv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float2 a = col[(8 * seg + j) * ROW];
+                const float v = zb_discriminate(a, p, atan_s);
+                dv[j] = (m0 + (uint64_t)(8 * seg + j) < n_out) ? v : 0.0f;
+                dl[k * DLROW + 8 * seg + j] = dv[j];
+                p = a;
+            }
+            const bool emit = tile >= t_begin;                        // the tile before the range only primes prevy
+            if (emit) {
+                float* dst = zb.d + (uint64_t)k * zb.d_stride + m0 + (uint64_t)(8 * seg);
+                reinterpret_cast<float4*>(dst)[0] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+                reinterpret_cast<float4*>(dst)[1] = make_float4(dv[4], dv[5], dv[6], dv[7]);
+            }
+            lds_barrier();
+            if (seg == T / 8 - 1) prevy[k] = p;                       // y[m0 + T - 1] for the next tile
+            // S_j of the tile's 2 x M sub-blocks (oracle order): four threads per sub-block sum 16
+            // terms each in sequence, S = (P0 + P1) + (P2 + P3)
+            if (emit && t < 8 * M) {
+                const int part = t & 3, kk = (t >> 2) & (M - 1), sb = t >> 6;
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    acc = acc + wts_s[63 - (16 * part + i)] * (double)dl[kk * DLROW + 64 * sb + 16 * part + i];
+                acc = acc + __shfl_down(acc, 1);
+                acc = acc + __shfl_down(acc, 2);
+                const uint64_t j = (m0 >> 6) + (uint64_t)sb;
+                if (part == 0 && j < zb.nsb) zb.S[(uint64_t)kk * zb.nsb + j] = acc;
+            }
+            // the staging of the next tile overwrites dl (= xs) only after its own barrier ... no:
+            lds_barrier();                                            // ... it writes xs first: wait for the S_j reads
+        }
+
+        if constexpr (FUSED && M == 40) {
             lds_barrier();
             // ---- 4. hard bits.  Thread <-> (channel k, phase j), samples m = 4 s + j: symbol 15 of
             //      the previous tile (its sample is carried in a register) completes that tile's
@@ -333,11 +407,14 @@ uint64_t PfbCtx::n_out_for(uint64_t n) const
     return n >= L ? (n - L) / D + 1u : 0u;
 }
 
-int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride)
+int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride,
+                const PfbZbTarget* zbt)
 {
     n_out = n_out_for(n);
     y_stride = (n_out + 64 + 1) & ~1ull;      // even: channel rows stay 16-byte aligned
-    if (!planes16) { if (int rc = d_y.ensure(y_stride * M * 8u)) return rc; }
+    if (!planes16 && !zbt) { if (int rc = d_y.ensure(y_stride * M * 8u)) return rc; }
+    PfbZbOut zb{};
+    if (zbt) zb = PfbZbOut{zbt->d, zbt->d_stride, zbt->S, zbt->nsb, zbt->atan_tab, zbt->iir_w};
     if (n_out == 0) return 0;
     SNOUT_HIP(hipEventRecord(ev_k0, st));
     // persistent workgroups (3 per CU by registers), each walks a contiguous range of tiles
@@ -348,19 +425,32 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
             hipLaunchKernelGGL((pfb_channelize<40, true>), dim3(nwg), dim3(PfbGeom<40>::NT), 0, st,
                                (const float2*)d_iq, n, n_out, n_tiles, tpw,
                                d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
+                               (float2*)nullptr, (uint64_t)0, planes16, plane_stride, zb);
         else
             hipLaunchKernelGGL((pfb_channelize<40, false>), dim3(nwg), dim3(PfbGeom<40>::NT), 0, st,
                                (const float2*)d_iq, n, n_out, n_tiles, tpw,
                                d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
+                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, zb);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
-        const uint32_t tpw = cdiv(n_tiles, grid_blocks), nwg = cdiv(n_tiles, tpw);
-        hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st,
-                           (const float2*)d_iq, n, n_out, n_tiles, tpw,
-                           d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                           d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
+        // 256-thread workgroups: four per CU fit (128 VGPRs, 29 KB LDS)
+        const uint32_t blocks16 = grid_blocks == 768u ? 1024u : grid_blocks;
+        const uint32_t tpw = cdiv(n_tiles, blocks16), nwg = cdiv(n_tiles, tpw);
+        if (zbt) {
+            // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
+            const uint64_t done = (uint64_t)n_tiles * PfbGeom<16>::T;
+            if (done < zbt->d_stride)
+                SNOUT_HIP(hipMemset2DAsync(zbt->d + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
+            hipLaunchKernelGGL((pfb_channelize<16, true>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st,
+                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
+                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
+                               (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0, zb);
+        } else {
+            hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st,
+                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
+                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
+                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, zb);
+        }
     }
     SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());

@@ -131,16 +131,25 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
     SNOUT_HIP(hipEventRecord(s.ev_t0, st));
     SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));   // the tail that last used this work set must be done
+    // fused wideband modes (unless the caller keeps channel IQ for the CHAN_IQ tap): BTLE hard bits
+    // straight into the bit planes, 802.15.4 discriminator output straight into the Zigbee context
     const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.reserved[0] & 1u);
+    const bool fused_zb = h->wide && h->cfg.proto == SNOUT_PROTO_ZIGBEE && !(h->cfg.reserved[0] & 1u);
     if (h->wide) {
         n_ch = h->pfb.n_out_for(s.n_in);
         BtleCtx& bw = btle_of(h, s);
         if (fused) { if (int rc = bw.reserve(n_ch)) return rc; }
+        PfbZbTarget zt{};
+        if (fused_zb) {
+            ZbCtx& z = zb_of(h, s);
+            if (int rc = z.reserve(n_ch)) return rc;
+            zt = z.pfb_target();
+        }
         SNOUT_HIP(hipEventRecord(s.ev_k0, st));
         if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
-                                bw.plane_stride)) return rc;
+                                bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_k1, st));
-        ch_iq = h->pfb.d_y.as<float>();
+        ch_iq = (fused_zb && n_ch >= 9u) ? nullptr : h->pfb.d_y.as<float>();
         ch_stride = h->pfb.y_stride;
     }
     if (h->cfg.proto == SNOUT_PROTO_BTLE) {

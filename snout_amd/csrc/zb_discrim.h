@@ -1,0 +1,41 @@
+// zb_discrim.h — the FM discriminator arithmetic of the 802.15.4 path, shared by zb_discrim
+// (zigbee.hip) and the fused M = 16 channelizer epilogue (pfb.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace snout {
+
+// a4: d[t] = fast_atan2f(Im(x[t] conj x[t-1]), Re(...)),  x[-1] = 0.  GNU Radio's table-driven
+// fast_atan2f (257-entry atan table, linear interpolation, octant fix-up).
+__device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* __restrict__ tab)
+{
+    // Straight-line form of the oracle's branches (same operations on the taken path, selected).
+    const float ya = fabsf(y), xa = fabsf(x);
+    const bool lt = ya < xa;
+    const float z = (lt ? ya : xa) / (lt ? xa : ya);         // 0/0 -> NaN, replaced below
+    const float a = z * 255.0f;
+    const int k = ((int)a) & 0xff;
+    const float t0 = tab[k];
+    const float interp = t0 + (tab[k + 1] - t0) * (a - (float)k);
+    const float base = z < 0.003921569f ? z : interp;
+    const float PI = 3.14159265358979323846f, H = 1.57079632679489661923f;
+    const bool xp = x >= 0.0f, yp = y >= 0.0f;
+    const float q_lt = xp ? (yp ? base : -base) : (yp ? PI - base : base - PI);
+    const float q_ge = yp ? (xp ? H - base : H + base) : (xp ? -H + base : -H - base);
+    const float ang = lt ? q_lt : q_ge;
+    return (ya > 0.0f || xa > 0.0f) ? ang : 0.0f;
+}
+
+
+// d = fast_atan2f(Im(a conj p), Re(a conj p)) with the products rounded first (contraction is off);
+// a non-finite result is defined as 0 (as the oracle).
+__device__ __forceinline__ float zb_discriminate(float2 a, float2 p, const float* __restrict__ tab)
+{
+    const float re = a.x * p.x + a.y * p.y;
+    const float im = a.y * p.x - a.x * p.y;
+    float v = fast_atan2f_tab(im, re, tab);
+    if (!(fabsf(v) <= 4.0f)) v = 0.0f;
+    return v;
+}
+
+}  // namespace snout

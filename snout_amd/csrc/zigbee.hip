@@ -19,6 +19,7 @@
 //   zb_stitch / zb_offsets / zb_scatter   first owned chip per lane, stream offsets, bit stream
 //   zb_walk     the sink FSM per lane on the bit stream (per-chip search, 32-chip symbol steps)
 #include "common.h"
+#include "zb_discrim.h"
 
 namespace snout {
 
@@ -32,28 +33,8 @@ static const float kMmseTapsHost[129][8] = {
 #include "mmse_taps.inc"
 };
 
-// ---------------------------------------------------------------------------------------------
-// a4: d[t] = fast_atan2f(Im(x[t] conj x[t-1]), Re(...)),  x[-1] = 0.  GNU Radio's table-driven
-// fast_atan2f (257-entry atan table, linear interpolation, octant fix-up).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* __restrict__ tab)
-{
-    // Straight-line form of the oracle's branches (same operations on the taken path, selected).
-    const float ya = fabsf(y), xa = fabsf(x);
-    const bool lt = ya < xa;
-    const float z = (lt ? ya : xa) / (lt ? xa : ya);         // 0/0 -> NaN, replaced below
-    const float a = z * 255.0f;
-    const int k = ((int)a) & 0xff;
-    const float t0 = tab[k];
-    const float interp = t0 + (tab[k + 1] - t0) * (a - (float)k);
-    const float base = z < 0.003921569f ? z : interp;
-    const float PI = 3.14159265358979323846f, H = 1.57079632679489661923f;
-    const bool xp = x >= 0.0f, yp = y >= 0.0f;
-    const float q_lt = xp ? (yp ? base : -base) : (yp ? PI - base : base - PI);
-    const float q_ge = yp ? (xp ? H - base : H + base) : (xp ? -H + base : -H - base);
-    const float ang = lt ? q_lt : q_ge;
-    return (ya > 0.0f || xa > 0.0f) ? ang : 0.0f;
-}
+// a4: the discriminator arithmetic (fast_atan2f_tab) lives in zb_discrim.h, shared with the fused
+// channelizer epilogue.
 
 constexpr uint32_t kTrFields = 9;  // tile record: cw lo/hi, d_lo lo/hi, d_hi lo/hi, nc, cstart, ii_start
 
@@ -1063,9 +1044,11 @@ int ZbCtx::enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipS
 {
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
     if (n < 9u) return 0;   // no interpolator window fits: nothing to launch
-    hipLaunchKernelGGL(zb_discrim, dim3(cdiv(d_stride, 1024), n_slots), dim3(256), 0, st, (const float2*)d_iq, n,
-                       iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(),
-                       d_S.as<double>());
+    if (d_iq) {             // otherwise the fused channelizer has already written d and S
+        hipLaunchKernelGGL(zb_discrim, dim3(cdiv(d_stride, 1024), n_slots), dim3(256), 0, st, (const float2*)d_iq, n,
+                           iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(),
+                           d_S.as<double>());
+    }
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
     hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
@@ -1077,6 +1060,11 @@ int ZbCtx::enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipS
                        (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
     SNOUT_HIP(hipGetLastError());
     return 0;
+}
+
+PfbZbTarget ZbCtx::pfb_target() const
+{
+    return PfbZbTarget{d_d.as<float>(), d_stride, d_S.as<double>(), nsb, d_atan.as<float>(), d_iirw.as<double>()};
 }
 
 // Tail (stitch, a7, ordered compaction into s.d_out / s.d_totals) on the handle's tail stream, so
