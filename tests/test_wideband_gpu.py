@@ -90,6 +90,31 @@ def test_wideband_zigbee_matches_oracle(oracle):
     assert found >= 0.9 * len(truth) and len(truth) > 10
 
 
+@pytest.mark.parametrize("n_out", [8, 9, 63, 127, 128, 129, 255, 256, 257, 128 * 5 + 31, 4096 + 700])
+def test_fused_zigbee_edges(oracle, n_out):
+    """Fused 802.15.4 channelizer around its tile (128 outputs), sub-block (64) and lane boundaries:
+    packets and the discriminator rows it writes equal the oracle's (channelize, then discriminate)."""
+    from snout_amd.rx import SnoutRx
+    from snout_amd._ffi import STAGE_ZB_DISCRIM
+    n = 256 + 8 * (n_out - 1) + 3
+    rng = np.random.default_rng(n_out)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    if n_out > 1000:        # some structure so that the sinks have something to find
+        xs, _ = synth.wideband_capture(1, n, seed=n_out, bins=[1, 9], mean_gap=3000.0, max_len=20)
+        x = xs[:n]
+    y = oracle.pfb(x, 16)
+    assert y.shape[1] == n_out
+    with SnoutRx(proto=1, n_channels=16) as rx:
+        got = rx.process(x, first_sample_index=77)
+        _same_packets(got, oracle.wideband_segment(x, 1, first_sample_index=77))
+        if n_out >= 9:
+            for slot in (0, 7, 15):
+                d = rx.soft(STAGE_ZB_DISCRIM, slot)
+                want = oracle.zb_discrim(y[slot])
+                assert d.size == want.size == n_out
+                assert np.array_equal(d.view(np.uint32), want.view(np.uint32)), slot
+
+
 def test_sharded_scan_equals_one_shot(oracle):
     """cfg #5 mechanics on one GPU: overlapping segments + dedup reproduce the one-shot result."""
     import torch
