@@ -117,7 +117,15 @@ __global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S,
     const uint64_t b1 = ((uint64_t)(li + 1) * core - warmup) / 64u;
     const double* s = S + (uint64_t)slot * nsb;
     double L = 0.0;
-    for (uint64_t j = b0; j < b1; j++) L = d64 * L + (j < nsb ? s[j] : 0.0);
+    uint64_t j = b0;
+    for (; j + 8u <= b1 && j + 8u <= nsb; j += 8u) {        // eight loads in flight per step
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = s[j + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) L = d64 * L + v[k];
+    }
+    for (; j < b1; j++) L = d64 * L + (j < nsb ? s[j] : 0.0);
     Lblk[g] = L;
 }
 
