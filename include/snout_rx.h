@@ -65,7 +65,7 @@ typedef struct snout_rx_cfg {
     uint32_t access_addr;     /* BTLE `-a` (btle.py:66); 0 -> 0x8E89BED6                         */
     uint32_t crc_init;        /* BTLE `-k` (btle.py:67); 0 -> 0x555555                           */
     uint32_t chip_threshold;  /* packet_sink(threshold) (top_block.py:67); 0 -> 10               */
-    uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 -> 4096           */
+    uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 -> 2048           */
     uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 512;
                                  multiples of 64, warm-up < core; the timing loop needs >= 256      */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */

@@ -185,7 +185,7 @@ def zb_discrim(iq: np.ndarray) -> np.ndarray:
     return d[:n]
 
 
-def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 4096,
+def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 2048,
                    warmup: int = 512, first_sample_index: int = 0, cap: int = 0) -> np.ndarray:
     a = _f32(iq)
     n = a.size // 2
@@ -199,7 +199,7 @@ def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core:
     return out[:n_out.value]
 
 
-def zigbee_lane_soft(iq: np.ndarray, lane: int = 0, core: int = 4096, warmup: int = 512,
+def zigbee_lane_soft(iq: np.ndarray, lane: int = 0, core: int = 2048, warmup: int = 512,
                      threshold: int = 10, cap: int = 1 << 17):
     a = _f32(iq)
     n = a.size // 2
@@ -241,7 +241,7 @@ def zigbee_bin_channel(b: int) -> int:
 
 
 def wideband_segment(iq: np.ndarray, proto: int, first_sample_index: int = 0, aa: int = 0x8E89BED6,
-                     crc_init: int = 0x555555, threshold: int = 10, core: int = 4096,
+                     crc_init: int = 0x555555, threshold: int = 10, core: int = 2048,
                      warmup: int = 512, cap: int = 0) -> np.ndarray:
     a = _f32(iq)
     n = a.size // 2

@@ -135,7 +135,7 @@ struct PfbCtx {
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
 struct ZbCtx {
-    uint32_t n_slots = 0, threshold = 10, core = 4096, warmup = 512;
+    uint32_t n_slots = 0, threshold = 10, core = 2048, warmup = 512;
     uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
     uint32_t n_waves = 0, nt = 0, tiles_per_slot = 0;   // waves of 64 lanes, 64-sample tiles per lane

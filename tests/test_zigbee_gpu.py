@@ -49,7 +49,7 @@ def test_soft_intermediates_within_tolerance(oracle):
             z = rx.soft(STAGE_ZB_DCREMOVED, lane)
             chips = rx.soft(STAGE_ZB_CHIPS, lane)
             wz, wc = oracle.zigbee_lane_soft(x, lane=lane)
-            m = min(z.size, 4096 + (512 if lane else 0))
+            m = min(z.size, 2048 + (512 if lane else 0))
             assert m > 1000 and np.max(np.abs(z[:m] - wz[:m])) <= TOL_DC
             assert chips.size == wc.size
             assert np.max(np.abs(chips - wc)) <= TOL_CHIPS

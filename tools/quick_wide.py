@@ -24,7 +24,7 @@ if "zb1" in which:
     t = torch.from_numpy(tile.view(np.float32)).cuda()
     rep = 24
     x = t.repeat(rep); x += 0.05 * torch.randn_like(x)
-    for core in (16384, 4096):
+    for core in (4096, 2048):
         rx = SnoutRx(proto=1, channel=11, zb_core=core)
         run(f"zigbee 1ch core={core} (expect {rep*len(truth)})", rx, x, rep * tile.size)
         del rx
