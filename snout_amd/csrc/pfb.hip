@@ -9,14 +9,17 @@
 //   u_m[r] = sum_p h[r + pM] x[mD + r + pM]           (M branches, P = 16 taps, D = M/2)
 //   y_k[m] = (-1)^{km} FFT_M(u_m)[k]
 //
-// Work split per tile of T output times (one workgroup):
-//   1. stage the (T-1)D + MP input samples in LDS (coalesced 8-B loads, read from HBM once; tiles
-//      overlap by MP - D samples, served by L2),
+// A workgroup walks a contiguous range of tiles of T output times; per tile:
+//   1. stage the (T-1)D + MP input samples in LDS: the MP - D samples shared with the previous
+//      tile are already there (moved to the front), the T D new ones arrive by 16-byte loads issued
+//      one tile ahead, so the input is read from HBM once,
 //   2. FIR: thread <-> (branch r, output parity e, group g).  Outputs m = e + 2i of one branch are
 //      a sliding dot product over the branch stream z[q] = x[r + eD + qM]: 23 LDS reads feed 8
 //      outputs x 16 taps, taps live in registers -> FMA-bound, not LDS-bound,
-//   3. FFT in two LDS passes (M = M1 M2): thread <-> (m, n2) does the M1-point DFT + twiddle,
-//      thread <-> (m, k1) does the M2-point DFT and writes y_k[m] with m fastest (coalesced).
+//   3. FFT in two passes that work in place on the FIR rows (M = M1 M2): thread <-> (m, n2) does the
+//      M1-point DFT + twiddle, thread <-> (m, k1) the M2-point DFT,
+//   4. either y_k[m] goes to HBM (16-byte stores, m fastest), or a fused epilogue consumes it from
+//      LDS: BTLE hard bits into the bit planes (M = 40), 802.15.4 discriminator rows (M = 16).
 // LDS rows are padded to M + 1 complex so column walks hit distinct banks.
 //
 // Roofline: at M = 40 the stage needs ~181 flop per input sample (FIR 128 + FFT), i.e. ~23 flop/B:
