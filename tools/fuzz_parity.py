@@ -1,0 +1,73 @@
+"""Randomised GPU == oracle parity sweep (developer tool): random sizes, lane shapes, densities and
+impairments for the four receive paths.  Prints the failing case and stops at the first mismatch."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from snout_amd import synth
+from snout_amd.rx import SnoutRx
+from oracle import oracle_py as oracle
+
+FIELDS = ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags", "aux")
+
+
+def same(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in FIELDS) and np.array_equal(a["bytes"], b["bytes"])
+
+
+def main(budget_s):
+    rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+    t_end = time.time() + budget_s
+    n_cases = {"btle": 0, "zigbee": 0, "btle40": 0, "zigbee16": 0}
+    while time.time() < t_end:
+        kind = rng.choice(list(n_cases))
+        seed = int(rng.integers(1 << 30))
+        first = int(rng.integers(0, 1 << 40))
+        if kind == "btle":
+            n = int(rng.integers(5, 1 << 19))
+            ch = int(rng.integers(0, 40))
+            x, _ = synth.btle_capture(n, channel=ch, seed=seed, mean_gap=float(rng.choice([300.0, 3000.0, 30000.0])))
+            with SnoutRx(proto=0, channel=ch) as rx:
+                got = rx.process(x, first_sample_index=first)
+            want, _ = oracle.btle_segment(x, channel=ch, first_sample_index=first)
+            desc = f"btle n={n} ch={ch} seed={seed}"
+        elif kind == "zigbee":
+            n = int(rng.integers(9, 1 << 19))
+            core = int(rng.choice([1024, 2048, 4096, 8192, 16384]))
+            warm = int(rng.choice([w for w in (256, 512, 1024, 2048) if w < core]))
+            x, _ = synth.zigbee_capture(n, seed=seed, mean_gap=float(rng.choice([400.0, 4000.0, 20000.0])),
+                                        cfo_max_hz=float(rng.choice([0.0, 40e3, 100e3])))
+            if rng.random() < 0.2:
+                x[int(rng.integers(0, n))] = np.nan
+            with SnoutRx(proto=1, channel=11, zb_core=core, zb_warmup=warm) as rx:
+                got = rx.process(x, first_sample_index=first)
+            want = oracle.zigbee_segment(x, channel=11, core=core, warmup=warm, first_sample_index=first)
+            desc = f"zigbee n={n} core={core} warm={warm} seed={seed}"
+        elif kind == "btle40":
+            n = int(rng.integers(640, 40 * 60000))
+            x, _ = synth.wideband_capture(0, n, seed=seed, bins=sorted(rng.choice(40, 6, replace=False).tolist()),
+                                          mean_gap=float(rng.choice([2000.0, 8000.0])))
+            x = x[:n]
+            with SnoutRx(proto=0, n_channels=40) as rx:
+                got = rx.process(x, first_sample_index=first)
+            want = oracle.wideband_segment(x, 0, first_sample_index=first)
+            desc = f"btle40 n={n} seed={seed}"
+        else:
+            n = int(rng.integers(256, 16 * 60000))
+            core = int(rng.choice([1024, 2048, 4096]))
+            x, _ = synth.wideband_capture(1, n, seed=seed, bins=sorted(rng.choice(16, 4, replace=False).tolist()),
+                                          mean_gap=float(rng.choice([3000.0, 12000.0])), max_len=40)
+            x = x[:n]
+            with SnoutRx(proto=1, n_channels=16, zb_core=core) as rx:
+                got = rx.process(x, first_sample_index=first)
+            want = oracle.wideband_segment(x, 1, first_sample_index=first, core=core)
+            desc = f"zigbee16 n={n} core={core} seed={seed}"
+        n_cases[kind] += 1
+        if not same(got, want):
+            print("MISMATCH:", desc, "first_index", first, len(got), len(want), flush=True)
+            return 1
+    print("fuzz ok:", n_cases, flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0))
