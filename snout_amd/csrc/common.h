@@ -123,7 +123,6 @@ struct PfbCtx {
     uint64_t n_out = 0, y_stride = 0;
     uint32_t grid_blocks = 768;      // persistent grid (256 CUs x 3 workgroups: 128 VGPRs, 36 KB LDS)
     DevBuf d_proto, d_tw, d_tw5, d_y;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     int init(uint32_t M);
     void destroy();
     uint64_t n_out_for(uint64_t n) const;

@@ -393,15 +393,12 @@ int PfbCtx::init(uint32_t M_)
     SNOUT_HIP(hipMemcpy(d_proto.p, proto, M * 16 * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_tw.p, tw, 2 * M * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_tw5.p, kTw5, 10 * 4, hipMemcpyHostToDevice));
-    SNOUT_HIP(hipEventCreate(&ev_k0));
-    SNOUT_HIP(hipEventCreate(&ev_k1));
     return 0;
 }
 
 void PfbCtx::destroy()
 {
     d_proto.release(); d_tw.release(); d_tw5.release(); d_y.release();
-    if (ev_k0) { (void)hipEventDestroy(ev_k0); (void)hipEventDestroy(ev_k1); ev_k0 = nullptr; }
 }
 
 uint64_t PfbCtx::n_out_for(uint64_t n) const
@@ -419,7 +416,6 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
     PfbZbOut zb{};
     if (zbt) zb = PfbZbOut{zbt->d, zbt->d_stride, zbt->S, zbt->nsb, zbt->atan_tab, zbt->iir_w};
     if (n_out == 0) return 0;
-    SNOUT_HIP(hipEventRecord(ev_k0, st));
     // persistent workgroups (3 per CU by registers), each walks a contiguous range of tiles
     if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
@@ -455,7 +451,6 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
                                d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, zb);
         }
     }
-    SNOUT_HIP(hipEventRecord(ev_k1, st));
     SNOUT_HIP(hipGetLastError());
     return 0;
 }

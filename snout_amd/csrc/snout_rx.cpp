@@ -129,7 +129,11 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
 {
     const float* ch_iq = s.iq;
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
-    SNOUT_HIP(hipEventRecord(s.ev_t0, st));
+    // Every event on the caller's stream is a barrier packet between consecutive front-end kernels
+    // (~8 us each): the narrowband BTLE path, whose kernel is the whole front end, reuses the pair
+    // around the kernel as start-of-segment and front-end-done events.
+    const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;
+    if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_t0, st));
     SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));   // the tail that last used this work set must be done
     // fused wideband modes (unless the caller keeps channel IQ for the CHAN_IQ tap): BTLE hard bits
     // straight into the bit planes, 802.15.4 discriminator output straight into the Zigbee context
@@ -160,8 +164,8 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         } else {
             if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s)) return rc;
         }
-        SNOUT_HIP(hipEventRecord(s.ev_front, st));
-        SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, s.ev_front, 0));
+        if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_front, st));
+        SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, nb_btle ? s.ev_k1 : s.ev_front, 0));
         if (int rc = b.enqueue_tail(n_ch, s.first_index, h->tail_stream, s)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, h->tail_stream));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], h->tail_stream));
@@ -551,7 +555,8 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     memset(out, 0, sizeof(*out));
     if (!h->last || !h->last->timed) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
     ResultSlot& s = *h->last;
-    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, s.ev_t0, s.ev_copy));
+    const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;     // see enqueue_segment
+    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, nb_btle ? h->hist_k0[s.hist_idx] : s.ev_t0, s.ev_copy));
     SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->hist_k0[s.hist_idx], h->hist_k1[s.hist_idx]));
     out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
     out->n_hits = s.h_totals[0];
