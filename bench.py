@@ -122,8 +122,8 @@ def main():
         if gather is not None:
             # RCCL gather of this step's records to rank 0, overlapped with the next step
             if len(gather.inflight) == 2:
-                gather.finish()
-            gather.start(pk)
+                gather.finish(views=True)       # records are in rank 0's host memory; no host-side copy
+            gather.start(pk, rx.last_records_device()[0])      # packed from the device copy: no upload
         return pk
 
     def run_steps(k):
@@ -157,7 +157,7 @@ def main():
 
     def drain():
         while gather is not None and gather.inflight:
-            gather.finish()
+            gather.finish(views=True)
 
     drain()
     fence()

@@ -133,6 +133,9 @@ int  snout_rx_submit_dev  (snout_rx* h, const float* iq_dev, uint64_t n_samples,
                            uint64_t first_sample_index, void* hip_stream);
 int  snout_rx_collect     (snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out);
 int  snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out);
+/* Device copy of the records of the segment collected last (same lifetime as the collect_view
+ * pointer): lets a multi-GPU gather take them GPU -> GPU (RCCL) without a trip through host memory. */
+int  snout_rx_last_records_dev(snout_rx* h, const snout_pkt** recs_dev, uint64_t* n_out);
 
 /* Page-locked host memory for `out`: records are then DMA'd straight into it (no staging copy).
  * Any other host pointer works too, through an internal pinned staging buffer. */

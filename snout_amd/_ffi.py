@@ -20,7 +20,7 @@ STAGE_BTLE_BITS, STAGE_CHAN_IQ, STAGE_ZB_DISCRIM, STAGE_ZB_DCREMOVED, STAGE_ZB_C
 
 EXPORTS = [
     "snout_rx_create", "snout_rx_destroy", "snout_rx_process", "snout_rx_process_dev",
-    "snout_rx_submit_dev", "snout_rx_collect", "snout_rx_collect_view",
+    "snout_rx_submit_dev", "snout_rx_collect", "snout_rx_collect_view", "snout_rx_last_records_dev",
     "snout_host_alloc", "snout_host_free", "snout_rx_soft", "snout_rx_profile",
     "snout_rx_profile_history", "snout_btle_format_line", "snout_rftap_encap",
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     lib.snout_rx_collect.restype = C.c_int
     lib.snout_rx_collect_view.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.snout_rx_collect_view.restype = C.c_int
+    lib.snout_rx_last_records_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.snout_rx_last_records_dev.restype = C.c_int
     lib.snout_host_alloc.argtypes = [C.c_size_t]
     lib.snout_host_alloc.restype = vp
     lib.snout_host_free.argtypes = [vp]

@@ -469,6 +469,17 @@ int snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out)
     return SNOUT_OK;
 }
 
+int snout_rx_last_records_dev(snout_rx* h, const snout_pkt** recs_dev, uint64_t* n_out)
+{
+    if (!h || !recs_dev || !n_out) return SNOUT_EINVAL;
+    *recs_dev = nullptr;
+    *n_out = 0;
+    if (!h->last) { set_last_error("no collected segment"); return SNOUT_EINVAL; }
+    *recs_dev = h->last->n_pkts ? h->last->d_out.as<snout_pkt>() : nullptr;
+    *n_out = h->last->n_pkts;
+    return SNOUT_OK;
+}
+
 int snout_rx_collect(snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out)
 {
     if (!out && cap) return SNOUT_EINVAL;

@@ -128,16 +128,22 @@ class AsyncRecordGather:
         self.slots = []
         for _ in range(2):
             send = torch.zeros((self.cap + 1) * self.width, dtype=torch.uint8, device=self.device)
+            # full 160-byte records land here first (one contiguous copy); the first `width` bytes
+            # of each are then packed into `send` on the device
+            stage = torch.zeros(self.cap * REC, dtype=torch.uint8, device=self.device) \
+                if (self.on_gpu and self.width < REC) else None
             recv = torch.zeros(self.world * (self.cap + 1) * self.width, dtype=torch.uint8,
                                device=self.device)
             host = torch.zeros(recv.shape, dtype=torch.uint8,
                                pin_memory=self.on_gpu) if self.rank == 0 else None
             ev = torch.cuda.Event() if self.on_gpu else None
             up = torch.cuda.Event() if self.on_gpu else None
-            self.slots.append(dict(send=send, recv=recv, host=host, ev=ev, up=up))
+            self.slots.append(dict(send=send, recv=recv, host=host, ev=ev, up=up, stage=stage))
         self.next = 0
 
-    def start(self, rec: np.ndarray) -> None:
+    def start(self, rec: np.ndarray, dev_ptr: int = 0) -> None:
+        """``dev_ptr``: device address of the same records (SnoutRx.last_records_device()); with the
+        nccl backend they are then packed straight from device memory, no upload."""
         torch = self.torch
         n = int(rec.size)
         while len(self.inflight) >= 2:
@@ -152,16 +158,28 @@ class AsyncRecordGather:
         self.next ^= 1
         hdr = np.zeros(self.width, dtype=np.uint8)
         hdr[:8] = np.frombuffer(np.uint64(n).tobytes(), dtype=np.uint8)
-        src = np.ascontiguousarray(rec).view(np.uint8).reshape(n, REC)[:, :self.width] if n else None
+        raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1) if n else None    # n x 160 bytes, a view
+        # No dependency on the caller's stream: the records are host memory that collect() has
+        # already waited for, and the slot's buffers were released by the finish() of its last use.
+        # (Waiting for the current stream would queue the exchange behind the front-end kernels of
+        # the segments submitted since.)
         ctx = torch.cuda.stream(self.stream) if self.on_gpu else _null_ctx()
-        if self.on_gpu:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with ctx:
             send = slot["send"]
             send[:self.width].copy_(torch.from_numpy(hdr), non_blocking=True)
             if n:
                 view = send[self.width:(n + 1) * self.width].view(n, self.width)
-                view.copy_(torch.from_numpy(src), non_blocking=True)
+                if self.on_gpu and dev_ptr:
+                    dev = _device_bytes(torch, dev_ptr, n * REC, self.device)
+                    view.copy_(dev.view(n, REC)[:, :self.width])
+                elif slot["stage"] is not None:
+                    # contiguous upload (a strided host-side gather of 52 k records costs ~8 ms), then
+                    # the narrowing copy as a device kernel
+                    st = slot["stage"][:n * REC]
+                    st.copy_(torch.from_numpy(raw), non_blocking=True)
+                    view.copy_(st.view(n, REC)[:, :self.width])
+                else:
+                    view.copy_(torch.from_numpy(raw.reshape(n, REC)[:, :self.width]), non_blocking=True)
             if self.on_gpu:
                 slot["up"].record(self.stream)       # the caller's record buffer may be reused after this
             if self.world > 1:
@@ -181,7 +199,11 @@ class AsyncRecordGather:
             for slot in self.inflight:
                 slot["up"].synchronize()
 
-    def finish(self) -> Optional[np.ndarray]:
+    def finish(self, views: bool = False):
+        """Records of the oldest started gather (rank 0; None elsewhere).  ``views=True`` returns a
+        list with one zero-copy view per rank into the pinned receive buffer (valid until the slot
+        is reused two start() calls later) instead of one concatenated array -- at 8 ranks the
+        concatenation is a 30 MB host copy per step."""
         if not self.inflight:
             return None
         slot = self.inflight.pop(0)
@@ -192,9 +214,22 @@ class AsyncRecordGather:
         host = slot["host"].numpy().reshape(self.world, (self.cap + 1) * self.width)
         parts = []
         for r in range(self.world):
-            n = int(np.frombuffer(host[r, :8].tobytes(), dtype="<u8")[0])
-            parts.append(host[r, self.width:(n + 1) * self.width].reshape(n, self.width))
-        return np.concatenate(parts).reshape(-1).view(self.dtype)
+            n = int(host[r, :8].view("<u8")[0])
+            parts.append(host[r, self.width:(n + 1) * self.width].view(self.dtype))
+        if views:
+            return parts
+        return np.concatenate(parts)
+
+
+class _DevMem:
+    """Minimal __cuda_array_interface__ holder so torch can view foreign device memory."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _device_bytes(torch, ptr: int, nbytes: int, device):
+    return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
 class _null_ctx:

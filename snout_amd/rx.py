@@ -139,6 +139,14 @@ class SnoutRx:
         view = np.frombuffer(buf, dtype=PKT_DTYPE)
         return view.copy() if copy else view
 
+    def last_records_device(self):
+        """(device pointer, count) of the records of the segment collected last — the device copy
+        behind the array collect() returned; valid until three more submits."""
+        ptr = C.c_void_p()
+        n = C.c_uint64(0)
+        _ffi.check(self._lib.snout_rx_last_records_dev(self._h, C.byref(ptr), C.byref(n)))
+        return (ptr.value or 0), int(n.value)
+
     def soft(self, stage: int, channel_slot: int = 0, cap: int = 0) -> np.ndarray:
         cap = cap or (1 << 24)
         out = np.zeros(cap, dtype=np.float32)

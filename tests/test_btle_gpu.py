@@ -165,17 +165,22 @@ def test_async_record_gather_over_rccl_world1():
         with SnoutRx(proto=0, channel=37) as rx:
             want = rx.process(t)
             outs = []
-            for i in range(4):
+            for i in range(6):
+                g.sync_uploads()
                 rx.submit(t)
                 if i:
                     pk = rx.collect(copy=False)
                     if len(g.inflight) == 2:
                         outs.append(g.finish())
-                    g.start(pk)
+                    # odd steps: upload from the pinned host view; even steps: packed straight from
+                    # the device copy of the records (snout_rx_last_records_dev)
+                    dev, n_dev = rx.last_records_device()
+                    assert n_dev == len(pk)
+                    g.start(pk, dev if i % 2 == 0 else 0)
             g.start(rx.collect(copy=False)) if len(g.inflight) < 2 else None
             while g.inflight:
                 outs.append(g.finish())
-        assert len(outs) >= 3
+        assert len(outs) >= 5
         for o in outs:
             assert o.dtype.itemsize == 80 and len(o) == len(want)
             assert np.array_equal(o["sample_index"], want["sample_index"])
