@@ -124,3 +124,31 @@ def test_stitched_lanes_find_what_the_sequential_receiver_finds(oracle, gap):
     assert sorted(bytes(p["bytes"][:p["len"]]) for p in lan if p["crc_ok"]) == sent
     assert sum(1 for p in lan if not p["crc_ok"]) <= max(2, len(truth) // 50)
     assert np.all(np.diff(lan["sample_index"].astype(np.int64)) > 0)
+
+
+def _golden_zigbee():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = json.load(open(os.path.join(here, "zigbee_ch15_expected.json")))
+    x = np.fromfile(os.path.join(here, "zigbee_ch15_4msps.cf32"), dtype=np.complex64)
+    return x, exp
+
+
+def _records_equal(pk, exp):
+    assert len(pk) == len(exp["records"])
+    for p, r in zip(pk, exp["records"]):
+        assert (int(p["sample_index"]), int(p["channel"]), int(p["len"]), int(p["crc_ok"]), int(p["lqi"]),
+                int(p["aux"])) == (r["sample_index"], r["channel"], r["len"], r["crc_ok"], r["lqi"], r["aux"])
+        assert bytes(p["bytes"][:p["len"]]).hex() == r["bytes"] and not p["bytes"][p["len"]:].any()
+
+
+def test_golden_zigbee_fixture(oracle):
+    """The committed capture decodes to the committed records (tests/golden/make_golden_zigbee.py):
+    pins the lane / stitching / sink rules against accidental change."""
+    x, exp = _golden_zigbee()
+    pk = oracle.zigbee_segment(x, channel=exp["channel"], threshold=exp["threshold"], core=exp["core"],
+                               warmup=exp["warmup"], first_sample_index=exp["first_sample_index"])
+    _records_equal(pk, exp)
+    sent = {s["psdu"] for s in exp["sent"]}
+    assert {r["bytes"] for r in exp["records"] if r["crc_ok"]} == sent

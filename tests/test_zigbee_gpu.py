@@ -115,3 +115,15 @@ def test_lane_shapes_match_oracle(oracle, core, warmup):
     if warmup >= 256:       # a 64-sample warm-up is accepted but too short for the timing loop to lock
         good = {bytes(p["bytes"][:p["len"]]) for p in got if p["crc_ok"]}
         assert sum(t.payload in good for t in truth) >= len(truth) - 1
+
+
+def test_golden_zigbee_fixture_on_gpu():
+    """The committed 802.15.4 capture through the C ABI with default lane shape == committed records."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_zigbee import _golden_zigbee, _records_equal
+    x, exp = _golden_zigbee()
+    with _rx(channel=exp["channel"]) as rx:
+        got = rx.process(x, first_sample_index=exp["first_sample_index"])
+    _records_equal(got, exp)
