@@ -17,19 +17,22 @@ from ._ffi import PKT_DTYPE
 REC = PKT_DTYPE.itemsize  # 160
 
 
-def shard_segments(n_total: int, seg_len: int, overlap: int, rank: int, world: int
-                   ) -> List[Tuple[int, int]]:
+def shard_segments(n_total: int, seg_len: int, overlap: int, rank: int, world: int,
+                   preroll: int = 0) -> List[Tuple[int, int]]:
     """Cut [0, n_total) into segments of seg_len samples that each extend `overlap` samples into
     the next one (so a packet straddling a cut is whole in the earlier segment), and deal them
-    round-robin: segment i -> rank i % world.  Returns this rank's [(start, stop), ...]."""
-    assert seg_len > 0 and overlap >= 0 and 0 <= rank < world
+    round-robin: segment i -> rank i % world.  Returns this rank's [(start, stop), ...].
+    ``preroll`` > 0 lets every segment but the first start that many samples early (a receiver
+    with a start-up transient settles there; its records from before i * seg_len are the previous
+    segment's to report)."""
+    assert seg_len > 0 and overlap >= 0 and preroll >= 0 and 0 <= rank < world
     out = []
     i = 0
     start = 0
     while start < n_total:
         stop = min(start + seg_len + overlap, n_total)
         if i % world == rank:
-            out.append((start, stop))
+            out.append((max(0, start - preroll), stop))
         start += seg_len
         i += 1
     return out

@@ -19,6 +19,10 @@ from .rx import SnoutRx
 # longest packet in channel samples at 4 Msps + loop warm-up
 BTLE_OVERLAP_CH = 1504
 ZIGBEE_OVERLAP_CH = 17024 + 2048
+# the single-pole DC estimate of the 802.15.4 chain (time constant 6250 samples) starts from zero in
+# every segment, as it does once at the start of the reference's stream: segments after the first
+# begin four time constants early and leave what they find there to the segment before
+ZIGBEE_PREROLL_CH = 4 * 6250
 
 
 class ShardedScan:
@@ -37,6 +41,8 @@ class ShardedScan:
         self.overlap = ov_ch * self.decim + self.pfb_taps            # in input samples
         step = 2 * self.decim                                         # keep PFB phase parity aligned
         self.seg_len = max(step, seg_len // step * step)
+        pre = 0 if proto == PROTO_BTLE else ZIGBEE_PREROLL_CH * self.decim
+        self.preroll = (pre + step - 1) // step * step                # in input samples
         self.rxs = [SnoutRx(proto=proto, channel=channel, n_channels=n_channels, device=device, **rx_kw)
                     for _ in range(max(1, handles))]
         self.rx = self.rxs[0]
@@ -50,7 +56,7 @@ class ShardedScan:
         import torch.distributed as tdist
         world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         rank = tdist.get_rank(group) if tdist.is_initialized() else 0
-        return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world)
+        return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world, self.preroll)
 
     # ---- a scan as a sequence of steps, so that several scans can share a GPU (run_concurrent)
     def start(self, n_total: int, source: Callable[[int, int], "object"], group=None) -> None:
@@ -62,7 +68,13 @@ class ShardedScan:
         ready.record(torch.cuda.current_stream())               # the capture was produced on this stream
         for st in self._streams:
             st.wait_event(ready)
+        import torch.distributed as tdist
         self._segs = self.my_segments(n_total, group)
+        world = tdist.get_world_size(group) if tdist.is_initialized() else 1
+        rank = tdist.get_rank(group) if tdist.is_initialized() else 0
+        # channel-sample index below which segment j's records belong to the segment before it
+        self._own_from = [((rank + j * world) * self.seg_len) // self.decim if (rank + j * world) else 0
+                          for j in range(len(self._segs))]
         self._source = source
         self._next = 0                  # next segment to submit
         self._done = 0                  # segments collected
@@ -87,7 +99,10 @@ class ShardedScan:
             self._next += 1
         elif self._done < self._next:
             j = self._done
-            self._parts.append(self.rxs[j % H].collect())      # segments of a handle complete in order
+            rec = self.rxs[j % H].collect()                     # segments of a handle complete in order
+            if self.preroll and self._own_from[j]:
+                rec = rec[rec["sample_index"] >= self._own_from[j]]
+            self._parts.append(rec)
             del self._alive[j]
             self._done += 1
 
