@@ -36,7 +36,8 @@ static const float kMmseTapsHost[129][8] = {
 // a4: the discriminator arithmetic (fast_atan2f_tab) lives in zb_discrim.h, shared with the fused
 // channelizer epilogue.
 
-constexpr uint32_t kTrFields = 9;  // tile record: cw lo/hi, d_lo lo/hi, d_hi lo/hi, nc, cstart, ii_start
+constexpr uint32_t kTrFields = 9;  // tile record: cw lo/hi, step codes of half A lo/hi, of half B lo/hi,
+                                   // nc | nc_A << 16, cstart, ii_start
 
 __device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t, uint32_t field, uint32_t row)
 {
@@ -232,8 +233,10 @@ __global__ __launch_bounds__(64) void zb_mm(
         // before the core end: 8 samples are enough.
         const uint32_t nz = (tile + 1u == nt) ? 8u : 64u;
         const uint32_t cstart = n_chips, ii_start = ii;
-        uint64_t d_lo = 0, d_hi = 0;
-        uint32_t nc = 0;
+        // window advances (step - 1 = 0..2) as 2-bit codes, one 64-bit word per half tile (a half
+        // holds at most 22 chips); the latest chip sits in the low bits
+        uint64_t dcode[2] = {0, 0};
+        uint32_t nc = 0, nc_a = 0;
         const bool cand_tile = tile == tb && li > 0u;
 #pragma unroll
         for (uint32_t hb = 0; hb < 64u; hb += 32u) {
@@ -267,7 +270,10 @@ __global__ __launch_bounds__(64) void zb_mm(
             const uint32_t staged = r0 + (nz < hb + 32u ? nz : hb + 32u);
             const uint32_t hi = staged < avail ? staged : avail;
             const uint32_t zorg = r0 + hb - 8u;                      // sample held by zrow[0] (mod 2^32)
-            while (ii < rce && ii + 8u <= hi) {
+            // windows must start before the core end and end inside what is staged
+            const uint32_t lim = hi >= 8u ? (rce < hi - 7u ? rce : hi - 7u) : 0u;
+            uint64_t dc = 0;
+            while (ii < lim) {
                 const int imu = (int)rintf(mu * 128.0f);
                 const float4 ta = tapsA[imu], tb4 = tapsB[imu];
                 const float* wv = &zrow[ii - zorg];                   // 8 consecutive samples
@@ -303,24 +309,24 @@ __global__ __launch_bounds__(64) void zb_mm(
                 const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
                 ii += step;
                 mu = mu - fl;
-                d_lo = (d_lo << 1) | ((step - 1u) & 1u);
-                d_hi = (d_hi << 1) | (((step - 1u) >> 1) & 1u);
+                dc = (dc << 2) | (uint64_t)(step - 1u);
                 nc++;
             }
+            dcode[hb >> 5] = dc;
+            if (hb == 0u) nc_a = nc;
         }
         n_chips += nc;
         // ---- tile record: chip c of the tile at bit 63 - c
         {
             const uint32_t sh = 64u - nc;
             const uint64_t cw = nc ? hist << sh : 0ull;
-            const uint64_t dl = nc ? d_lo << sh : 0ull, dh = nc ? d_hi << sh : 0ull;
             TR[tr_index(w, nt, tile, 0, l)] = (uint32_t)cw;
             TR[tr_index(w, nt, tile, 1, l)] = (uint32_t)(cw >> 32);
-            TR[tr_index(w, nt, tile, 2, l)] = (uint32_t)dl;
-            TR[tr_index(w, nt, tile, 3, l)] = (uint32_t)(dl >> 32);
-            TR[tr_index(w, nt, tile, 4, l)] = (uint32_t)dh;
-            TR[tr_index(w, nt, tile, 5, l)] = (uint32_t)(dh >> 32);
-            TR[tr_index(w, nt, tile, 6, l)] = nc;
+            TR[tr_index(w, nt, tile, 2, l)] = (uint32_t)dcode[0];
+            TR[tr_index(w, nt, tile, 3, l)] = (uint32_t)(dcode[0] >> 32);
+            TR[tr_index(w, nt, tile, 4, l)] = (uint32_t)dcode[1];
+            TR[tr_index(w, nt, tile, 5, l)] = (uint32_t)(dcode[1] >> 32);
+            TR[tr_index(w, nt, tile, 6, l)] = nc | (nc_a << 16);
             TR[tr_index(w, nt, tile, 7, l)] = cstart;
             TR[tr_index(w, nt, tile, 8, l)] = ii_start;
         }
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ T
     const uint32_t t0 = (g % lanes_per_slot) ? first_tile : 0u;
 #pragma unroll 4
     for (uint32_t t = t0; t < nt; t++) {
-        const uint32_t nc = TR[tr_index(w, nt, t, 6, row)];
+        const uint32_t nc = TR[tr_index(w, nt, t, 6, row)] & 0xFFFFu;
         const uint32_t c = TR[tr_index(w, nt, t, 7, row)];   // lane chip index of the tile's first chip
         const uint64_t cw = (uint64_t)TR[tr_index(w, nt, t, 0, row)] | ((uint64_t)TR[tr_index(w, nt, t, 1, row)] << 32);
         const uint32_t lo = f > c ? f : c;
@@ -790,12 +796,21 @@ __global__ __launch_bounds__(256) void zb_walk(
                         const uint32_t mid = (lo + hi2) >> 1;
                         if (TR[tr_index(w, nt, mid, 7, row)] <= j) lo = mid; else hi2 = mid;
                     }
+                    // chip i of that tile: its window start = the tile's first window start + the steps
+                    // of the chips before it (2-bit codes step - 1, half A then half B, latest chip low)
                     const uint32_t i = j - TR[tr_index(w, nt, lo, 7, row)];
-                    const uint64_t dl = (uint64_t)TR[tr_index(w, nt, lo, 2, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 3, row)] << 32);
-                    const uint64_t dh = (uint64_t)TR[tr_index(w, nt, lo, 4, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 5, row)] << 32);
-                    const uint64_t top = i ? ~0ull << (64u - i) : 0ull;
-                    const uint32_t rel = TR[tr_index(w, nt, lo, 8, row)] + i + (uint32_t)__popcll(dl & top) +
-                                         2u * (uint32_t)__popcll(dh & top);
+                    const uint32_t ncw = TR[tr_index(w, nt, lo, 6, row)];
+                    const uint32_t n_a = ncw >> 16, n_b = (ncw & 0xFFFFu) - n_a;
+                    const uint64_t ca = (uint64_t)TR[tr_index(w, nt, lo, 2, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 3, row)] << 32);
+                    const uint64_t cb = (uint64_t)TR[tr_index(w, nt, lo, 4, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 5, row)] << 32);
+                    auto code_sum = [](uint64_t word, uint32_t n_in, uint32_t first) -> uint32_t {
+                        // sum of the codes of the first `first` chips of a word holding n_in chips
+                        if (first == 0u) return 0u;
+                        const uint64_t x = word >> (2u * (n_in - first));
+                        return (uint32_t)__popcll(x & 0x5555555555555555ull) + 2u * (uint32_t)__popcll(x & 0xAAAAAAAAAAAAAAAAull);
+                    };
+                    const uint32_t ia = i < n_a ? i : n_a, ib = i < n_a ? 0u : i - n_a;
+                    const uint32_t rel = TR[tr_index(w, nt, lo, 8, row)] + i + code_sum(ca, n_a, ia) + code_sum(cb, n_b, ib);
                     const uint64_t cs = (uint64_t)(gt % lanes_per_slot) * core;
                     const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
                     snout_pkt* p = &stage[(size_t)g * K + n_pk];
