@@ -18,6 +18,7 @@
 //               window advances as 64-bit words per 64-sample tile
 //   zb_stitch / zb_offsets / zb_scatter   first owned chip per lane, stream offsets, bit stream
 //   zb_walk     the sink FSM per lane on the bit stream (per-chip search, 32-chip symbol steps)
+#include <type_traits>
 #include "common.h"
 #include "zb_discrim.h"
 
@@ -237,7 +238,6 @@ __global__ __launch_bounds__(64) void zb_mm(
         // holds at most 22 chips); the latest chip sits in the low bits
         uint64_t dcode[2] = {0, 0};
         uint32_t nc = 0, nc_a = 0;
-        const bool cand_tile = tile == tb && li > 0u;
 #pragma unroll
         for (uint32_t hb = 0; hb < 64u; hb += 32u) {
             if (hb < nz) {
@@ -273,45 +273,51 @@ __global__ __launch_bounds__(64) void zb_mm(
             // windows must start before the core end and end inside what is staged
             const uint32_t lim = hi >= 8u ? (rce < hi - 7u ? rce : hi - 7u) : 0u;
             uint64_t dc = 0;
-            while (ii < lim) {
-                const int imu = (int)rintf(mu * 128.0f);
-                const float4 ta = tapsA[imu], tb4 = tapsB[imu];
-                const float* wv = &zrow[ii - zorg];                   // 8 consecutive samples
-                float acc = 0.0f;
-                acc = __builtin_fmaf(ta.x, wv[7], acc);
-                acc = __builtin_fmaf(ta.y, wv[6], acc);
-                acc = __builtin_fmaf(ta.z, wv[5], acc);
-                acc = __builtin_fmaf(ta.w, wv[4], acc);
-                acc = __builtin_fmaf(tb4.x, wv[3], acc);
-                acc = __builtin_fmaf(tb4.y, wv[2], acc);
-                acc = __builtin_fmaf(tb4.z, wv[1], acc);
-                acc = __builtin_fmaf(tb4.w, wv[0], acc);
-                const float o = acc;
-                if constexpr (TAP) { if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o; }
-                hist = (hist << 1) | (o > 0.0f ? 1ull : 0ull);
-                t_last = ii * 128u + (uint32_t)imu;
-                if (cand_tile && ii + 3u - rcs <= 8u && cand_n < kMaxCand) {
-                    if (cand_n == 0u) c0 = n_chips + nc;
-                    cand_keys[(size_t)g * kMaxCand + cand_n] = t_last;
-                    cand_n++;
-                    hist_cand = hist;
-                }
-                const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
-                last = o;
-                omega = omega + gain_omega * mm;
-                {
-                    const float x = omega - omega_mid;
-                    const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
-                    omega = omega_mid + c;
-                }
-                mu = mu + omega + gain_mu * mm;
-                const float fl = floorf(mu);
-                const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
-                ii += step;
-                mu = mu - fl;
-                dc = (dc << 2) | (uint64_t)(step - 1u);
-                nc++;
+            auto mm_steps = [&](auto cand_tag) {
+                constexpr bool CAND = decltype(cand_tag)::value;
+                while (ii < lim) {
+                    const int imu = (int)rintf(mu * 128.0f);
+                    const float4 ta = tapsA[imu], tb4 = tapsB[imu];
+                    const float* wv = &zrow[ii - zorg];                   // 8 consecutive samples
+                    float acc = 0.0f;
+                    acc = __builtin_fmaf(ta.x, wv[7], acc);
+                    acc = __builtin_fmaf(ta.y, wv[6], acc);
+                    acc = __builtin_fmaf(ta.z, wv[5], acc);
+                    acc = __builtin_fmaf(ta.w, wv[4], acc);
+                    acc = __builtin_fmaf(tb4.x, wv[3], acc);
+                    acc = __builtin_fmaf(tb4.y, wv[2], acc);
+                    acc = __builtin_fmaf(tb4.z, wv[1], acc);
+                    acc = __builtin_fmaf(tb4.w, wv[0], acc);
+                    const float o = acc;
+                    if constexpr (TAP) { if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o; }
+                    hist = (hist << 1) | (o > 0.0f ? 1ull : 0ull);
+                    t_last = ii * 128u + (uint32_t)imu;
+                    if constexpr (CAND) {       // only the tile that holds the lane's core start records candidates
+                        if (li > 0u && ii + 3u - rcs <= 8u && cand_n < kMaxCand) {
+                            if (cand_n == 0u) c0 = n_chips + nc;
+                            cand_keys[(size_t)g * kMaxCand + cand_n] = t_last;
+                            cand_n++;
+                            hist_cand = hist;
+                        }
+                    }
+                    const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+                    last = o;
+                    omega = omega + gain_omega * mm;
+                    {
+                        const float x = omega - omega_mid;
+                        const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+                        omega = omega_mid + c;
+                    }
+                    mu = mu + omega + gain_mu * mm;
+                    const float fl = floorf(mu);
+                    const uint32_t step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;    // 1..3 for finite input
+                    ii += step;
+                    mu = mu - fl;
+                    dc = (dc << 2) | (uint64_t)(step - 1u);
+                    nc++;
             }
+            };
+            if (tile == tb) mm_steps(std::true_type{}); else mm_steps(std::false_type{});
             dcode[hb >> 5] = dc;
             if (hb == 0u) nc_a = nc;
         }
