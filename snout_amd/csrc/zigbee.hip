@@ -678,13 +678,15 @@ __global__ __launch_bounds__(256) void zb_walk(
     // a few latency-bound waves that run beside the next segment's front end: issue them first
     __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= total_lanes) return;
-    const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool exists = g < total_lanes;            // lanes past the end still help their wave decode
+    const uint32_t gs = exists ? g : 0u;
+    const uint32_t slot = gs / lanes_per_slot, li = gs % lanes_per_slot;
     const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
     const unsigned long long* mt = match + (uint64_t)slot * stream_words;
-    const uint32_t total = slot_total[slot];
-    const uint32_t own0 = offs[g];
-    const uint32_t own1 = li + 1u < lanes_per_slot ? offs[g + 1u] : total;
+    const uint32_t total = exists ? slot_total[slot] : 0u;
+    const uint32_t own0 = offs[gs];
+    const uint32_t own1 = li + 1u < lanes_per_slot ? offs[gs + 1u] : total;
     SinkState s;
     enter_search(s);
     s.byte_index = s.packetlen = s.packetlen_cnt = s.payload_cnt = 0;
@@ -693,99 +695,130 @@ __global__ __launch_bounds__(256) void zb_walk(
     uint32_t q = own0 > kSinkWarmChips ? own0 - kSinkWarmChips : 0u;
     ChipReader rd;
     rd.open(sw, q);
-    while (q < total) {
-        if (s.state == 0 && s.preamble_cnt == 0) {
-            // searching: one test per chip
-            if (q >= own1) break;                       // idle at or past the next lane's first chip
-            // The register was cleared at chip q.  While fewer than 32 chips are in, the test sees a
-            // zero-filled register: 31 explicit tests on the 64 chips that start at q ...
-            const uint32_t lim = own1 < total ? own1 : total;
-            rd.seek(q);
-            const uint32_t bo = q & 63u;
-            const uint64_t x64 = bo ? (rd.cur << bo) | (rd.n1 >> (64u - bo)) : rd.cur;
-            const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
-            uint32_t pm = 0;                            // bit k: match after chip q + k, k = 0..30
-#pragma unroll
-            for (uint32_t k = 0; k < 31u; k++) {
-                const uint32_t reg = (uint32_t)(x64 >> (63u - k));
-                pm |= (uint32_t)((uint32_t)__popc((reg & 0x7FFFFFFEu) ^ sym0) < th) << k;
-            }
-            bool hit = false;
-            uint32_t qh = 0;
-            if (pm) {
-                qh = q + (uint32_t)__ffs((int)pm) - 1u;
-                hit = qh < lim;
-            }
-            if (!pm) {
-                // ... then the precomputed full-register matches, a word at a time
-                uint32_t qs = q + 31u;
-                while (qs < lim) {
-                    const uint64_t mw = mt[qs >> 6] & (~0ull >> (qs & 63u));
-                    if (mw) { qh = (qs & ~63u) + (uint32_t)__clzll((long long)mw); hit = qh < lim; break; }
-                    qs = (qs & ~63u) + 64u;
-                }
-            }
-            if (hit) {
-                q = qh + 1u;
-                rd.seek(q);
-            }
-            if (!hit) break;                            // ran to the end of the lane (or of the stream) idle
-            s.preamble_cnt = 1;                         // chip_cnt stays 0: the boundary is 32 chips on
-            s.trigger = q - 1u;
-            continue;
-        }
-        // inside a (candidate) frame
+    bool alive = exists && q < total;
+    auto bcast = [](uint32_t v, int src) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+    while (__ballot(alive) != 0ull) {
         bool fin = false, stepped = false;
-        if (s.state == 2 && s.byte_index == 0 && s.packetlen - s.payload_cnt >= 4 && q + 255u < total) {
-            // Payload, at least four bytes to go: decode eight symbols at once.  Their windows come
-            // straight from memory (eight independent 16-byte loads) and the eight nearest-word
-            // searches are independent, so a lane that is alone in a long frame is not bound by the
-            // latency of one symbol after the other.  If any of the eight is further than the
-            // threshold from every word, the one-symbol path below takes over (same result).
-            uint32_t nw[8];
-            uint32_t worst = 0;
-#pragma unroll
-            for (uint32_t j2 = 0; j2 < 8u; j2++) {
-                const uint32_t qe = q + 31u + 32u * j2;             // last chip of symbol j2
+        // ---- payload, cooperatively.  A lane inside the payload of a frame (state 2, at a byte
+        //      boundary, at least two bytes to go) would otherwise take one symbol per iteration while
+        //      the other 63 lanes of the wave wait: instead the whole wave decodes up to 64 symbols of
+        //      that lane's frame at once (lane l takes symbol l), the valid prefix is consumed in whole
+        //      bytes, and a symbol further than the threshold from every word is left to the
+        //      one-symbol path below, which gives up the frame exactly as the sink does.
+        const bool elig = alive && s.state == 2 && s.byte_index == 0 && s.packetlen - s.payload_cnt >= 2 &&
+                          q + 63u < total;
+        uint64_t need = __ballot(elig);
+        const uint64_t pb_me = (exists && n_pk < K) ? (uint64_t)(uintptr_t)stage[(size_t)g * K + n_pk].bytes : 0ull;
+        while (need != 0ull) {
+            const int src = __builtin_ctzll(need);
+            need &= need - 1ull;
+            const uint32_t q0 = bcast(q, src), tot0 = bcast(total, src);
+            const uint32_t rem = bcast((uint32_t)(s.packetlen - s.payload_cnt), src);
+            const unsigned long long* sw0 = (const unsigned long long*)(uintptr_t)(
+                (uint64_t)bcast((uint32_t)(uintptr_t)sw, src) | ((uint64_t)bcast((uint32_t)((uint64_t)(uintptr_t)sw >> 32), src) << 32));
+            uint32_t S = 2u * rem < 64u ? 2u * rem : 64u;
+            const uint32_t fit = (tot0 - q0) >> 5;                 // symbols whose last chip is in the stream
+            S = S < fit ? S : fit;
+            uint32_t nwv = 0xFF00u;                                 // distance 255: invalid
+            if (lane < S) {
+                const uint32_t qe = q0 + 31u + 32u * lane;          // last chip of symbol `lane`
                 const uint32_t wi2 = qe >> 6, sh = 63u - (qe & 63u);
-                const uint64_t cur = sw[wi2], prv = wi2 ? sw[wi2 - 1u] : 0ull;
+                const uint64_t cur = sw0[wi2], prv = wi2 ? sw0[wi2 - 1u] : 0ull;
                 uint64_t xw = cur >> sh;
                 if (sh > 32u) xw |= prv << (64u - sh);
-                nw[j2] = nearest_word((uint32_t)xw);
-                worst = (nw[j2] >> 8) > worst ? (nw[j2] >> 8) : worst;
+                nwv = nearest_word((uint32_t)xw);
             }
-            if (worst < th) {
-                uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
-#pragma unroll
-                for (uint32_t b2 = 0; b2 < 4u; b2++) {
-#pragma unroll
-                    for (uint32_t h2 = 0; h2 < 2u; h2++)
-                        if (s.lqi_cnt < 8) { s.lqi += 32 - (nw[2u * b2 + h2] >> 8); s.lqi_cnt++; }
-                    const uint32_t byte = (nw[2u * b2] & 15u) | ((nw[2u * b2 + 1u] & 15u) << 4);
-                    if (pb) pb[s.packetlen_cnt] = (uint8_t)byte;
-                    s.c2 = s.c1; s.c1 = s.c0; s.c0 = crc16_step(s.c0, byte);
-                    s.b_prev = s.b_last; s.b_last = byte;
-                    s.packetlen_cnt++;
-                    s.payload_cnt++;
-                }
-                s.packet_byte = (int)s.b_last;
-                q += 256u;
+            const uint64_t okm = __ballot(lane < S && (nwv >> 8) < th);
+            const uint32_t first_bad = ~okm ? (uint32_t)__builtin_ctzll(~okm) : 64u;
+            const uint32_t vb = (first_bad < S ? first_bad : S) >> 1;       // whole bytes in the valid prefix
+            if (vb == 0u) continue;                                  // the one-symbol path takes it from here
+            // link quality: the first eight symbols of a frame
+            uint32_t lqi0 = bcast(s.lqi, src), lqc0 = bcast(s.lqi_cnt, src);
+            for (uint32_t j = 0; j < 2u * vb && lqc0 < 8u; j++) { lqi0 += 32u - (bcast(nwv, (int)j) >> 8); lqc0++; }
+            // bytes: low nibble first
+            const uint32_t nib = nwv & 15u;
+            const uint32_t byte = nib | (((uint32_t)__shfl_down((int)nib, 1)) << 4);    // even lanes
+            const uint32_t cnt0 = bcast((uint32_t)s.packetlen_cnt, src);
+            uint8_t* pb0 = (uint8_t*)(uintptr_t)((uint64_t)bcast((uint32_t)pb_me, src) |
+                                                 ((uint64_t)bcast((uint32_t)(pb_me >> 32), src) << 32));
+            if (pb0 && !(lane & 1u) && lane < 2u * vb) pb0[cnt0 + (lane >> 1)] = (uint8_t)byte;
+            // running FCS and the last two bytes: sequential over the bytes, on uniform values
+            uint32_t c0 = bcast(s.c0, src), c1 = bcast(s.c1, src), c2 = bcast(s.c2, src);
+            uint32_t bp = bcast(s.b_prev, src), bl = bcast(s.b_last, src);
+            for (uint32_t k = 0; k < vb; k++) {
+                const uint32_t bk = bcast(byte, (int)(2u * k));
+                c2 = c1; c1 = c0; c0 = crc16_step(c0, bk);
+                bp = bl; bl = bk;
+            }
+            if ((int)lane == src) {
+                s.lqi = lqi0; s.lqi_cnt = lqc0;
+                s.c0 = c0; s.c1 = c1; s.c2 = c2; s.b_prev = bp; s.b_last = bl;
+                s.packetlen_cnt += (int)vb; s.payload_cnt += (int)vb;
+                s.packet_byte = (int)bl;
+                q += 64u * vb;
                 fin = s.payload_cnt >= s.packetlen;
                 stepped = true;
             }
         }
-        if (!stepped) {
-            // one symbol: jump to the next symbol boundary
-            const uint32_t qb = q + 31u;                    // q is the first chip of the symbol
-            if (qb >= total) break;                         // the stream ends inside the frame
-            rd.seek(qb);
-            s.shift = rd.window32(qb);
-            uint8_t* pb = (n_pk < K) ? stage[(size_t)g * K + n_pk].bytes : nullptr;
-            const int state_before = s.state;
-            fin = sink_symbol(s, th, pb);
-            if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
-            q = qb + 1u;
+        if (alive && !stepped) {
+            if (s.state == 0 && s.preamble_cnt == 0) {
+                // searching: one test per chip
+                if (q >= own1) {
+                    alive = false;                      // idle at or past the next lane's first chip
+                } else {
+                    // The register was cleared at chip q.  While fewer than 32 chips are in, the test sees
+                    // a zero-filled register: 31 explicit tests on the 64 chips that start at q ...
+                    const uint32_t lim = own1 < total ? own1 : total;
+                    rd.seek(q);
+                    const uint32_t bo = q & 63u;
+                    const uint64_t x64 = bo ? (rd.cur << bo) | (rd.n1 >> (64u - bo)) : rd.cur;
+                    const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
+                    uint32_t pm = 0;                    // bit k: match after chip q + k, k = 0..30
+#pragma unroll
+                    for (uint32_t k = 0; k < 31u; k++) {
+                        const uint32_t reg = (uint32_t)(x64 >> (63u - k));
+                        pm |= (uint32_t)((uint32_t)__popc((reg & 0x7FFFFFFEu) ^ sym0) < th) << k;
+                    }
+                    bool hit = false;
+                    uint32_t qh = 0;
+                    if (pm) {
+                        qh = q + (uint32_t)__ffs((int)pm) - 1u;
+                        hit = qh < lim;
+                    } else {
+                        // ... then the precomputed full-register matches, a word at a time
+                        uint32_t qs = q + 31u;
+                        while (qs < lim) {
+                            const uint64_t mw = mt[qs >> 6] & (~0ull >> (qs & 63u));
+                            if (mw) { qh = (qs & ~63u) + (uint32_t)__clzll((long long)mw); hit = qh < lim; break; }
+                            qs = (qs & ~63u) + 64u;
+                        }
+                    }
+                    if (hit) {
+                        q = qh + 1u;
+                        rd.seek(q);
+                        s.preamble_cnt = 1;             // chip_cnt stays 0: the boundary is 32 chips on
+                        s.trigger = q - 1u;
+                    } else {
+                        alive = false;                  // ran to the end of the lane (or of the stream) idle
+                    }
+                }
+            } else {
+                // inside a (candidate) frame, one symbol: jump to the next symbol boundary
+                const uint32_t qb = q + 31u;            // q is the first chip of the symbol
+                if (qb >= total) {
+                    alive = false;                      // the stream ends inside the frame
+                } else {
+                    rd.seek(qb);
+                    s.shift = rd.window32(qb);
+                    uint8_t* pb = (uint8_t*)(uintptr_t)pb_me;
+                    const int state_before = s.state;
+                    fin = sink_symbol(s, th, pb);
+                    if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
+                    q = qb + 1u;
+                }
+            }
         }
+        if (alive && q >= total) alive = false;
         if (fin) {
             // Sinks may first match different preamble symbols but find the SFD at the same chip:
             // the frame belongs to the lane that owns that chip.
@@ -840,7 +873,7 @@ __global__ __launch_bounds__(256) void zb_walk(
             enter_search(s);
         }
     }
-    lane_cnt[g] = n_pk;
+    if (exists) lane_cnt[g] = n_pk;
 }
 
 // Ordered compaction of per-lane records: lane g holds min(lane_cnt[g], K) records.
