@@ -696,6 +696,8 @@ __global__ __launch_bounds__(256) void zb_walk(
     ChipReader rd;
     rd.open(sw, q);
     bool alive = exists && q < total;
+    uint32_t pf_w = 0xFFFFFFF0u;                    // match words fetched ahead for the next search: index,
+    uint64_t pf_m0 = 0, pf_m1 = 0;                  // words pf_w and pf_w + 1
     auto bcast = [](uint32_t v, int src) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
     while (__ballot(alive) != 0ull) {
         bool fin = false, stepped = false;
@@ -785,10 +787,13 @@ __global__ __launch_bounds__(256) void zb_walk(
                         qh = q + (uint32_t)__ffs((int)pm) - 1u;
                         hit = qh < lim;
                     } else {
-                        // ... then the precomputed full-register matches, a word at a time
+                        // ... then the precomputed full-register matches, a word at a time; the first two
+                        // words were requested an iteration ago when this restart was foreseeable
                         uint32_t qs = q + 31u;
                         while (qs < lim) {
-                            const uint64_t mw = mt[qs >> 6] & (~0ull >> (qs & 63u));
+                            const uint32_t wq = qs >> 6;
+                            const uint64_t word = wq == pf_w ? pf_m0 : (wq == pf_w + 1u ? pf_m1 : mt[wq]);
+                            const uint64_t mw = word & (~0ull >> (qs & 63u));
                             if (mw) { qh = (qs & ~63u) + (uint32_t)__clzll((long long)mw); hit = qh < lim; break; }
                             qs = (qs & ~63u) + 64u;
                         }
@@ -812,6 +817,11 @@ __global__ __launch_bounds__(256) void zb_walk(
                     s.shift = rd.window32(qb);
                     uint8_t* pb = (uint8_t*)(uintptr_t)pb_me;
                     const int state_before = s.state;
+                    if (state_before == 0) {            // most such checks fail: the search resumes at qb + 1
+                        pf_w = (qb + 32u) >> 6;
+                        pf_m0 = mt[pf_w];
+                        pf_m1 = mt[pf_w + 1u];
+                    }
                     fin = sink_symbol(s, th, pb);
                     if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
                     q = qb + 1u;
