@@ -241,7 +241,7 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
  * chip completing its SFD (its sample_index is where THAT sink first matched the preamble).
  * With core >= n (one lane) this is the reference's sequential receiver.
  */
-#define ORACLE_ZB_SINK_WARM 1024u
+#define ORACLE_ZB_SINK_WARM 512u
 
 typedef struct {
     uint64_t n_chips;        /* chips produced by the lane's M&M */

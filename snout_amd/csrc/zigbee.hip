@@ -153,7 +153,7 @@ constexpr int kZRow = 41;          // per-lane z buffer: 8 samples of history + 
 // MMSE table in LDS as two float4 arrays (taps 0-3, taps 4-7 of every row): one ds_read_b128 each,
 // 16-B slot = row mod 16, so the 16 lanes of a read group spread over all slots
 constexpr uint32_t kMaxCand = 12;
-constexpr uint32_t kSinkWarmChips = 1024;   // sink warm-up on the stitched stream (ORACLE_ZB_SINK_WARM)
+constexpr uint32_t kSinkWarmChips = 512;    // sink warm-up on the stitched stream (ORACLE_ZB_SINK_WARM)
 
 // What a lane hands to the stitcher (see oracle_zigbee.c "Stitching").
 struct ZbLaneOut {
