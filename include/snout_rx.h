@@ -70,8 +70,9 @@ typedef struct snout_rx_cfg {
                                  multiples of 64, warm-up < core; the timing loop needs >= 256      */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
-    uint32_t reserved[4];     /* [0] bit 0: wideband BTLE keeps channel IQ in HBM (unfused; needed for
-                                 the SNOUT_STAGE_CHAN_IQ tap), default is the fused bit slicer    */
+    uint32_t reserved[4];     /* [0] bit 0: a wideband handle keeps channel IQ in HBM (unfused kernels;
+                                 needed for the SNOUT_STAGE_CHAN_IQ tap).  Default: the channelizer
+                                 feeds the BTLE bit planes / the 802.15.4 discriminator rows directly */
 } snout_rx_cfg;
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
