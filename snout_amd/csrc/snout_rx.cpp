@@ -95,7 +95,10 @@ struct snout_rx {
     snout_rx_cfg cfg;
     int device = 0;
     bool wide = false;
-    BtleCtx btle, btle2;      // two work sets: the tail of segment i overlaps the front end of i+1
+    // Work sets: the tail of segment i overlaps the front end of i+1.  BTLE has three, so that with
+    // three segments in flight the set a new segment takes was released by a segment already
+    // collected (no wait to enqueue); the much larger Zigbee sets come in two.
+    BtleCtx btle, btle2, btle3;
     ZbCtx zb2;                // (second Zigbee work set; the first is `zb`)
     hipStream_t tail_stream = nullptr;
     ZbCtx zb;
@@ -103,7 +106,7 @@ struct snout_rx {
     DevBuf d_iq;              // staging for snout_rx_process (host input)
     static constexpr int kSlots = 3;    // segments in flight: front end i+1 is queued before copy i-1 lands
     ResultSlot slots[kSlots];
-    hipEvent_t ws_free[2] = {nullptr, nullptr};   // last tail that used BTLE work set k has finished
+    hipEvent_t ws_free[3] = {nullptr, nullptr, nullptr};   // the last tail that used work set k has finished
     uint64_t n_submitted = 0;
     hipStream_t copy_stream = nullptr;
     int head = 0, pending = 0;          // ring of submitted, not yet collected segments
@@ -118,7 +121,10 @@ struct snout_rx {
     uint64_t last_n = 0, last_nch = 0, last_pkts = 0;
 };
 
-static BtleCtx& btle_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->btle2 : h->btle; }
+static BtleCtx& btle_of(snout_rx* h, const ResultSlot& s)
+{
+    return s.work_set == 0 ? h->btle : (s.work_set == 1 ? h->btle2 : h->btle3);
+}
 static ZbCtx& zb_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->zb2 : h->zb; }
 
 // Enqueue every kernel of one segment, results into slot s.  No host synchronisation.
@@ -134,7 +140,10 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // around the kernel as start-of-segment and front-end-done events.
     const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;
     if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_t0, st));
-    SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));   // the tail that last used this work set must be done
+    // the tail that last used this work set must be done; usually it is, and a wait that is not
+    // enqueued is one barrier packet less between two front-end kernels
+    if (hipEventQuery(h->ws_free[s.work_set]) != hipSuccess)
+        SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));
     // fused wideband modes (unless the caller keeps channel IQ for the CHAN_IQ tap): BTLE hard bits
     // straight into the bit planes, 802.15.4 discriminator output straight into the Zigbee context
     const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.reserved[0] & 1u);
@@ -297,6 +306,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         uint16_t ch = (uint16_t)c.channel;
         rc = h->btle.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
         if (!rc) rc = h->btle2.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
+        if (!rc) rc = h->btle3.init(1, &ch, c.access_addr, c.crc_init, c.max_hits);
         if (rc) goto fail;
     } else if (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 1) {
         if (c.channel < 11 || c.channel > 26) { set_last_error("Zigbee channel %u", c.channel); goto fail; }
@@ -319,6 +329,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits)
                                          : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle2.init(M, chs, c.access_addr, c.crc_init, c.max_hits);
+        if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle3.init(M, chs, c.access_addr, c.crc_init, c.max_hits);
         if (!rc && c.proto == SNOUT_PROTO_ZIGBEE) rc = h->zb2.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (rc) goto fail;
     } else {
@@ -327,7 +338,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         goto fail;
     }
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         if (hipEventCreate(&h->ws_free[k]) != hipSuccess) { rc = SNOUT_EHIP; goto fail; }
     }
     for (int i = 0; i < snout_rx::kHist; i++) {
@@ -364,13 +375,14 @@ void snout_rx_destroy(snout_rx* h)
     (void)hipDeviceSynchronize();
     h->btle.destroy();
     h->btle2.destroy();
+    h->btle3.destroy();
     if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
     h->zb.destroy();
     h->zb2.destroy();
     h->pfb.destroy();
     h->d_iq.release();
     for (auto& s : h->slots) s.destroy();
-    for (int k = 0; k < 2; k++) if (h->ws_free[k]) (void)hipEventDestroy(h->ws_free[k]);
+    for (int k = 0; k < 3; k++) if (h->ws_free[k]) (void)hipEventDestroy(h->ws_free[k]);
     for (int i = 0; i < snout_rx::kHist; i++) {
         if (h->hist_k0[i]) (void)hipEventDestroy(h->hist_k0[i]);
         if (h->hist_k1[i]) (void)hipEventDestroy(h->hist_k1[i]);
@@ -406,7 +418,7 @@ int snout_rx_submit_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
     }
     SNOUT_HIP(hipSetDevice(h->device));
     ResultSlot& s = h->slots[(h->head + h->pending) % snout_rx::kSlots];
-    s.work_set = (int)(h->n_submitted++ & 1u);
+    s.work_set = (int)(h->n_submitted++ % (h->cfg.proto == SNOUT_PROTO_BTLE ? 3u : 2u));
     s.iq = iq_dev;
     s.n_in = n_samples;
     s.first_index = first_sample_index;
