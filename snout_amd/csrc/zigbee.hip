@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void zb_iir_scan(const double* __restrict__ Lb
 // ---------------------------------------------------------------------------------------------
 // a5-a6: lanes (IIR + Mueller & Mueller), chips out.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kMmWaves = 4;   // waves per zb_mm workgroup
 constexpr int kZRow = 41;          // per-lane z buffer: 8 samples of history + half a 64-sample tile, odd stride
 // MMSE table in LDS as two float4 arrays (taps 0-3, taps 4-7 of every row): one ds_read_b128 each,
 // 16-B slot = row mod 16, so the 16 lanes of a read group spread over all slots
@@ -172,7 +173,7 @@ struct ZbLaneOut {
 // stored as the tile's record.  No sink here: chips go to the stitched stream (zb_scatter) and the
 // sinks run on bits (zb_walk).
 template <bool TAP>
-__global__ __launch_bounds__(64) void zb_mm(
+__global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     const float* __restrict__ d, uint64_t d_stride, uint64_t n, uint32_t nt, uint32_t lanes_per_slot,
     uint32_t total_lanes, uint32_t core, uint32_t warmup, const float* __restrict__ mmse,
     const double* __restrict__ lp_in,
@@ -180,10 +181,13 @@ __global__ __launch_bounds__(64) void zb_mm(
     float* __restrict__ soft_z, float* __restrict__ soft_chips, uint32_t soft_lane, uint32_t soft_cap,
     uint32_t* __restrict__ soft_n)
 {
-    __shared__ float zb[64 * kZRow];
+    // kMmWaves independent waves per workgroup share one copy of the tap table (LDS decides how many
+    // waves a CU holds: 10.5 KB of rows per wave + 4.1 KB of taps per workgroup)
+    __shared__ float zb_all[kMmWaves * 64 * kZRow];
     __shared__ float4 tapsA[129], tapsB[129];
-    const uint32_t l = threadIdx.x, w = blockIdx.x;
-    for (uint32_t i = l; i < 129u; i += 64u) {
+    const uint32_t l = threadIdx.x & 63u, w = blockIdx.x * kMmWaves + (threadIdx.x >> 6);
+    float* zb = &zb_all[(threadIdx.x >> 6) * 64u * kZRow];
+    for (uint32_t i = threadIdx.x; i < 129u; i += kMmWaves * 64u) {
         tapsA[i] = make_float4(mmse[i * 8u + 0u], mmse[i * 8u + 1u], mmse[i * 8u + 2u], mmse[i * 8u + 3u]);
         tapsB[i] = make_float4(mmse[i * 8u + 4u], mmse[i * 8u + 5u], mmse[i * 8u + 6u], mmse[i * 8u + 7u]);
     }
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(64) void zb_mm(
     const uint32_t avail = active && n > s0 ? (uint32_t)((n - s0) < (uint64_t)(rce + 64u) ? (n - s0) : (rce + 64u)) : 0u;
     const uint32_t tb = warmup >> 6;                        // the tile that holds the stitch candidates
     __syncthreads();
+    if (w * 64u >= total_lanes) return;                     // a wave past the last lane (no records of its own)
 
     const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
     const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
@@ -1080,7 +1085,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     float* sc = d_soft.as<float>() + kSoftCap;
     uint32_t* sn = (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap);
     // re-run the lanes with the tap on (rewrites identical tile records)
-    hipLaunchKernelGGL(zb_mm<true>, dim3(n_waves), dim3(64), 0, nullptr, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
+    hipLaunchKernelGGL(zb_mm<true>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, nullptr, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
                        sz, sc, lane, (uint32_t)kSoftCap, sn);
@@ -1126,7 +1131,7 @@ int ZbCtx::enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipS
     hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
                        lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
                        d_lp_in.as<double>());
-    hipLaunchKernelGGL(zb_mm<false>, dim3(n_waves), dim3(64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
+    hipLaunchKernelGGL(zb_mm<false>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
                        (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
