@@ -13,6 +13,10 @@ Multi-GPU: capture segments shard across ranks with no data-path collective (wea
 rank processes its own 1e9-sample segment); decoded packet records are gathered to rank 0 with
 RCCL inside the timed region.
 
+`--workload` selects one of the other SURVEY §8d configurations (cfg3: 40-channel BTLE wideband,
+cfg4: 16-channel 802.15.4 wideband, zigbee1: single-channel 802.15.4) with the same contract; the
+default, and the line the round is judged on, is cfg2.
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the stream the
 dominant kernel runs on; `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded
 sample of the same workload on this host's cores.
@@ -35,14 +39,42 @@ TILE = 1 << 22                  # samples in the host-generated, noise-free pack
 SIGMA = 0.05
 
 
-def make_workload(n_samples: int, seed: int, device):
-    """Synthetic capture in HBM: a seeded tile of GFSK advertising packets (exponential gaps,
-    random CFO/phase/length, SURVEY §8d cfg #2) repeated to n_samples, plus independent AWGN on
-    every sample generated on the device. Returns (float32 tensor [2n], expected CRC-ok count,
-    set of expected PDUs)."""
-    import torch
+WORKLOADS = {
+    # name: (proto, n_channels, channel, default samples per GPU, record bytes gathered, metric, description)
+    "cfg2": (0, 1, 37, 1e9, 80, "complex-IQ Msamples/s through BTLE demod+correlate+decode",
+             "cfg2: single-channel BTLE (ch37) GFSK demod + access-address correlate + dewhiten/CRC"),
+    "cfg3": (0, 40, 0, 40 * (1 << 22), 80,
+             "wideband complex-IQ Msamples/s through 40-channel PFB + BTLE demod+correlate+decode",
+             "cfg3: 80 Msps wideband -> 40-channel polyphase channelizer -> BTLE receive on every channel"),
+    "cfg4": (1, 16, 0, 16 * (1 << 23), 160,
+             "wideband complex-IQ Msamples/s through 16-channel PFB + 802.15.4 receive",
+             "cfg4: 32 Msps wideband -> 16-channel polyphase channelizer -> 802.15.4 receive on every channel"),
+    "zigbee1": (1, 1, 11, 1e9, 160, "complex-IQ Msamples/s through 802.15.4 O-QPSK receive",
+                "single-channel 802.15.4 (ch11): discriminator + DC removal + M&M clock recovery + packet sink"),
+}
+
+
+def make_tile(workload: str, seed: int):
+    """Noise-free host tile of the workload's traffic and its truth list."""
     from snout_amd import synth
-    tile, truth = synth.btle_capture(TILE, channel=37, seed=seed, noise=False)
+    if workload == "cfg2":
+        return synth.btle_capture(TILE, channel=37, seed=seed, noise=False)
+    if workload == "zigbee1":
+        return synth.zigbee_capture(TILE, channel=11, seed=seed, noise=False)
+    if workload == "cfg3":
+        return synth.wideband_capture(0, 40 * (1 << 16), seed=seed, sigma=0.0)
+    if workload == "cfg4":
+        return synth.wideband_capture(1, 16 * (1 << 17), seed=seed, sigma=0.0)
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def make_workload(n_samples: int, seed: int, device, workload: str = "cfg2"):
+    """Synthetic capture in HBM: a seeded tile of packets (exponential gaps, random CFO/phase/
+    length) repeated to n_samples, plus independent AWGN on every sample generated on
+    the device. Returns (float32 tensor [2n], expected CRC-ok count, set of expected PDUs)."""
+    import torch
+    tile, truth = make_tile(workload, seed)
+    TILE = tile.size
     t = torch.from_numpy(tile.view(np.float32)).to(device)
     x = torch.empty(2 * n_samples, dtype=torch.float32, device=device)
     g = torch.Generator(device=device)
@@ -56,13 +88,26 @@ def make_workload(n_samples: int, seed: int, device):
         seg.mul_(SIGMA).add_(t[:hi - lo])
     full = n_samples // TILE
     rem = n_samples - full * TILE
-    expect = full * len(truth) + sum(1 for p in truth if p.sample_index + 1600 < rem)
+    if workload == "cfg2":
+        expect = full * len(truth) + sum(1 for p in truth if p.sample_index + 1600 < rem)
+    else:
+        # truth indices of the wideband tiles are at the channel rate and 802.15.4 frames are up to
+        # 4256 samples long: count whole tiles only, and allow the frames a repetition cuts short
+        # (cfg4: the synthetic 2 MHz raster makes adjacent 802.15.4 channels overlap spectrally,
+        # DESIGN.md §6.7 -- with all 16 bins busy about half of the frames survive, on the oracle too)
+        expect = int((0.4 if workload == "cfg4" else 0.9) * full * len(truth))
     pdus = {p.payload for p in truth}
     torch.cuda.synchronize(device)
     return x, expect, pdus
 
 
-def cpu_baseline(x_dev, n_sample: int, passes: int):
+# bounded CPU sample per workload: ~10-30 s of single-thread oracle time for the three passes
+CPU_SAMPLES = {"cfg2": 2.5e8, "cfg3": 40 * (1 << 21), "cfg4": 16 * (1 << 21), "zigbee1": 1 << 26}
+CPU_SOURCE = {"cfg2": "oracle/oracle_btle.c", "cfg3": "oracle/oracle_pfb.c + oracle_btle.c",
+              "cfg4": "oracle/oracle_pfb.c + oracle_zigbee.c", "zigbee1": "oracle/oracle_zigbee.c"}
+
+
+def cpu_baseline(x_dev, n_sample: int, passes: int, workload: str = "cfg2"):
     """Time the CPU oracle (single thread) on the first n_sample samples of the workload."""
     from oracle import oracle_py
     oracle_py.lib()
@@ -71,7 +116,12 @@ def cpu_baseline(x_dev, n_sample: int, passes: int):
     n_pk = 0
     for _ in range(passes):
         t0 = time.perf_counter()
-        pk, _ = oracle_py.btle_segment(host, channel=37, cap=max(1024, n_sample // 2048))
+        if workload == "cfg2":
+            pk, _ = oracle_py.btle_segment(host, channel=37, cap=max(1024, n_sample // 2048))
+        elif workload == "zigbee1":
+            pk = oracle_py.zigbee_segment(host, channel=11)
+        else:
+            pk = oracle_py.wideband_segment(host, proto=0 if workload == "cfg3" else 1)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         n_pk = len(pk)
@@ -83,8 +133,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=float, default=1e9, help="complex samples per GPU per step")
-    ap.add_argument("--cpu-samples", type=float, default=2.5e8)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--samples", type=float, default=0,
+                    help="complex input samples per GPU per step (default: the workload's size)")
+    ap.add_argument("--cpu-samples", type=float, default=0,
+                    help="samples of the CPU baseline leg (default: ~10-30 s of oracle time)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sync", action="store_true",
                     help="one segment at a time (no submit/collect pipelining); for profiling")
@@ -115,14 +168,15 @@ def main():
     from snout_amd.rx import SnoutRx
     from snout_amd import dist as sdist
 
-    n = int(args.samples)
-    x, expect, pdus = make_workload(n, seed=2 + rank, device=device)
-    rx = SnoutRx(proto=0, channel=37, device=local_rank)
+    proto, n_ch, channel, n_default, rec_width, metric, descr = WORKLOADS[args.workload]
+    n = int(args.samples or n_default)
+    x, expect, pdus = make_workload(n, seed=2 + rank, device=device, workload=args.workload)
+    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=local_rank)
 
     # Pipelined steps: up to three segments are in flight, so the next front-end kernel is already
     # queued when the previous one ends and the record D2H (copy stream) overlaps compute.  Every step's records are
     # in host memory (and gathered to rank 0) before the timed region ends.
-    gather = sdist.AsyncRecordGather(device, width=80) if world > 1 else None
+    gather = sdist.AsyncRecordGather(device, width=rec_width) if world > 1 else None
 
     def finish_one():
         pk = rx.collect(copy=False)
@@ -185,7 +239,8 @@ def main():
     # correctness of the timed work: every generated packet decoded with a good CRC
     local = rx.process(x, first_sample_index=rank * n)
     n_ok = int(local["crc_ok"].sum())
-    seen = {bytes(p["bytes"][:p["len"] - 3]) for p in local[:4096] if p["crc_ok"]}
+    fcs = 3 if proto == 0 else 0        # BTLE records carry PDU + CRC24, truth holds the PDU; 802.15.4: PSDU incl. FCS
+    seen = {bytes(p["bytes"][:p["len"] - fcs]) for p in local[:4096] if p["crc_ok"]}
     assert n_ok >= expect, f"rank {rank}: decoded {n_ok} CRC-ok packets, expected >= {expect}"
     assert seen <= pdus, "decoded a PDU that was never transmitted"
     prof = rx.profile()
@@ -199,10 +254,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tpath):       # PMC-derived HBM bytes per launch of the same workload
             tj = json.load(open(tpath))
-            if tj.get("workload_samples") == n and tj.get("kernel") == prof.dominant_name:
+            if (args.workload == "cfg2" and tj.get("workload_samples") == n
+                    and tj.get("kernel") == prof.dominant_name):
                 traffic = tj["traffic_bytes_per_launch"]
         out = {
-            "metric": "complex-IQ Msamples/s through BTLE demod+correlate+decode",
+            "metric": metric,
             "value": total_samples / dt / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -214,13 +270,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg2: single-channel BTLE (ch37) GFSK demod + access-address "
-                                   "correlate + dewhiten/CRC, %.3g cf32 samples per GPU resident in HBM"
-                                   % n,
+            "config": {"workload": "%s, %.3g cf32 samples per GPU resident in HBM" % (descr, n),
                        "samples_per_gpu": n, "packets_per_gpu": int(len(local)),
                        "decoded_pkts_per_s": len(local) * world * args.steps / dt,
                        "sharding": "segments per rank, RCCL gather of 160-B records" if world > 1
                                    else "single segment",
+                       "decoded_crc_ok_per_gpu": n_ok, "expected_crc_ok_per_gpu": expect,
                        "stepping": "one segment at a time" if args.sync else
                                    "pipelined: record D2H of step i overlaps step i+1"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -231,11 +286,11 @@ def main():
                          "algorithmic_bytes": algo_bytes},
         }
         if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
-            ns = int(min(args.cpu_samples, n))
-            v, n_pk, _ = cpu_baseline(x, ns, passes=3)
+            ns = int(min(args.cpu_samples or CPU_SAMPLES[args.workload], n))
+            v, n_pk, _ = cpu_baseline(x, ns, passes=3, workload=args.workload)
             out["cpu_baseline"] = {"value": v, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                    "sample": "first %.3g samples of the same workload, best of 3 "
-                                             "passes, oracle/oracle_btle.c single thread" % ns}
+                                             "passes, %s single thread" % (ns, CPU_SOURCE[args.workload])}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

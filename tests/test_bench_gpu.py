@@ -51,3 +51,21 @@ def test_two_ranks_share_the_gpu_over_gloo():
     assert KEYS <= set(d) and "cpu_baseline" not in d      # the CPU baseline is timed at N = 1 only
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["samples_per_gpu"] == 60000000
+
+
+@pytest.mark.parametrize("workload,samples,cpu,name", [
+    ("cfg3", 40 * (1 << 18), 40 * (1 << 16), "pfb_channelize<40>"),
+    ("cfg4", 16 * (1 << 19), 16 * (1 << 17), "pfb_channelize<16>"),
+    ("zigbee1", 1 << 23, 1 << 21, "zb_discrim..zb_walk"),
+])
+def test_other_workloads_keep_the_contract(workload, samples, cpu, name):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3",
+                        "--warmup", "1", "--samples", str(samples), "--cpu-samples", str(cpu)],
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["config"]["workload"].startswith(workload.replace("zigbee1", "single-channel 802"))
+    assert d["roofline"]["kernel"] == name and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["traffic"] is None
+    c = d["config"]
+    assert c["decoded_crc_ok_per_gpu"] >= c["expected_crc_ok_per_gpu"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["value"] > d["cpu_baseline"]["value"]
