@@ -36,6 +36,14 @@ extern "C" {
 #define SNOUT_PROTO_BTLE   0u
 #define SNOUT_PROTO_ZIGBEE 1u
 
+/* input sample formats (snout_rx_cfg.reserved[1]).  Integer samples stand for the cf32 samples
+ * v * 2^-7 (sc8) / v * 2^-15 (sc16): conversion and scale are exact in fp32, so results are bit-
+ * identical to processing the converted capture as cf32. */
+#define SNOUT_FMT_CF32 0u   /* interleaved float32 I,Q (numpy.complex64, gr_complex), 8 B/sample       */
+#define SNOUT_FMT_SC8  1u   /* interleaved int8 I,Q: HackRF transfers, the input of upstream btle_rx
+                               (SURVEY Appendix A.1), 2 B/sample                                     */
+#define SNOUT_FMT_SC16 2u   /* interleaved int16 I,Q (USRP sc16 captures), 4 B/sample                */
+
 /* error codes */
 #define SNOUT_OK          0
 #define SNOUT_EINVAL     -1   /* bad argument / configuration                      */
@@ -72,7 +80,8 @@ typedef struct snout_rx_cfg {
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
     uint32_t reserved[4];     /* [0] bit 0: a wideband handle keeps channel IQ in HBM (unfused kernels;
                                  needed for the SNOUT_STAGE_CHAN_IQ tap).  Default: the channelizer
-                                 feeds the BTLE bit planes / the 802.15.4 discriminator rows directly */
+                                 feeds the BTLE bit planes / the 802.15.4 discriminator rows directly
+                                 [1] SNOUT_FMT_* of every iq pointer handed to this handle (0 = cf32) */
 } snout_rx_cfg;
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
@@ -99,7 +108,7 @@ typedef struct snout_rx_prof {
     float    ms_dominant;     /* the dominant streaming kernel alone                             */
     uint32_t dominant_launches;
     uint32_t n_hits;          /* candidate hits before resolution (BTLE) / lanes (Zigbee)        */
-    uint64_t bytes_algorithmic; /* 8 B x input samples + 160 B x packets            */
+    uint64_t bytes_algorithmic; /* 8 B (cf32; sc8 2, sc16 4) x input samples + 160 B x packets */
     char     dominant_name[48];
 } snout_rx_prof;
 
@@ -108,7 +117,8 @@ typedef struct snout_rx snout_rx;
 int  snout_rx_create (const snout_rx_cfg* cfg, snout_rx** out);
 void snout_rx_destroy(snout_rx* h);
 
-/* One capture segment, synchronous. iq = interleaved cf32 (re,im), n_samples complex samples.
+/* One capture segment, synchronous. iq = interleaved (re,im) in the handle's sample format (cf32
+ * unless cfg.reserved[1] says otherwise), 16-byte aligned, n_samples complex samples.
  * Packets are written in ascending (channel, sample_index) order. *n_out receives the number of
  * packets found (may exceed cap -> SNOUT_EOVERFLOW, first cap records valid).
  *
@@ -119,9 +129,9 @@ void snout_rx_destroy(snout_rx* h);
  * snout_rx_process      : iq in HOST memory; copied H->D (PCIe-inclusive path).
  * snout_rx_process_dev  : iq already resident in DEVICE memory (HBM); hip_stream is a hipStream_t
  *                         (NULL = the legacy default stream). out is HOST memory. */
-int  snout_rx_process    (snout_rx* h, const float* iq_host, uint64_t n_samples,
+int  snout_rx_process    (snout_rx* h, const void* iq_host, uint64_t n_samples,
                           uint64_t first_sample_index, snout_pkt* out, uint64_t cap, uint64_t* n_out);
-int  snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
+int  snout_rx_process_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
                           uint64_t first_sample_index, void* hip_stream,
                           snout_pkt* out, uint64_t cap, uint64_t* n_out);
 
@@ -130,7 +140,7 @@ int  snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
  * hands out its records (collect_view: a pointer into the handle's pinned buffer, valid until three
  * more submits).  The record D2H of segment i runs on an internal copy stream and overlaps the
  * kernels of segment i+1.  iq_dev must stay valid and unchanged until its collect returns. */
-int  snout_rx_submit_dev  (snout_rx* h, const float* iq_dev, uint64_t n_samples,
+int  snout_rx_submit_dev  (snout_rx* h, const void* iq_dev, uint64_t n_samples,
                            uint64_t first_sample_index, void* hip_stream);
 int  snout_rx_collect     (snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out);
 int  snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out);

@@ -159,6 +159,15 @@ def btle_segment(iq: np.ndarray, channel: int = 37, aa: int = 0x8E89BED6, crc_in
     return out[:n_out.value], hits[:min(n_hits.value, hits.size)]
 
 
+def from_int(a: np.ndarray) -> np.ndarray:
+    """Interleaved int8 / int16 IQ -> the cf32 capture it stands for (include/snout_rx.h
+    SNOUT_FMT_SC8 / SC16: v * 2^-7 / v * 2^-15, exact in float32).  The oracle's definition of the
+    integer input formats is: run the cf32 algorithm on this."""
+    a = np.ascontiguousarray(a)
+    scale = {np.dtype(np.int8): 2.0 ** -7, np.dtype(np.int16): 2.0 ** -15}[a.dtype]
+    return (a.astype(np.float32) * np.float32(scale)).astype(np.float32)
+
+
 # ---- Zigbee ------------------------------------------------------------------------------------
 def zb_chip_map() -> np.ndarray:
     return np.array(lib().oracle_zb_chip_map()[:16], dtype=np.uint32)

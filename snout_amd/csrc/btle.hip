@@ -18,6 +18,7 @@
 // Roofline: btle_demod_corr is HBM-bound, 8 B read per complex sample (+1/64 warm-up re-read,
 // +0.125 B/sample plane write). Everything after it is O(candidates).
 #include "common.h"
+#include "iq_fmt.h"
 
 namespace snout {
 
@@ -78,17 +79,57 @@ __device__ __forceinline__ void append_hits(const bool hit[4], uint32_t lane, ui
 //  the overlapping half of each lane's 64 B); taking the 4 following samples from the next lane by
 //  cross-lane shuffle instead of the overlapping load: +-0; a persistent grid pulling chunks from
 //  an atomic ticket: -5 %.  Software-pipelining the loads: +9 %.)
-template <int DEPTH>
+// Integer input (FMT sc8 / sc16, iq_fmt.h): the lane's 8 samples are 16 / 32 bytes; the bit is the
+// same comparison on the converted values (sc8: in integers, every product is exact either way;
+// sc16: in fp32 like the cf32 path, a 30-bit product rounds).
+template <int FMT> struct K1Row {
+    static constexpr uint32_t kLoads = FMT == kFmtCf32 ? 4u : (FMT == kFmtSc16 ? 2u : 1u);   // 16-byte loads per lane and row
+    static constexpr uint32_t kLaneBytes = 4u * fmt_bytes(FMT), kRowBytes = 256u * fmt_bytes(FMT);
+    u32x4 v[kLoads];
+};
+
+template <int FMT>
+__device__ __forceinline__ void k1_bits(const K1Row<FMT>& q, bool b[4])
+{
+    if constexpr (FMT == kFmtCf32) {
+        const f32x4 v0 = __builtin_bit_cast(f32x4, q.v[0]), v1 = __builtin_bit_cast(f32x4, q.v[1]);
+        const f32x4 v2 = __builtin_bit_cast(f32x4, q.v[2]), v3 = __builtin_bit_cast(f32x4, q.v[3]);
+        // bit[n] = (I[n]*Q[n+4]) > (I[n+4]*Q[n]); two roundings, no contraction
+        b[0] = (v0.x * v2.y) > (v2.x * v0.y);
+        b[1] = (v0.z * v2.w) > (v2.z * v0.w);
+        b[2] = (v1.x * v3.y) > (v3.x * v1.y);
+        b[3] = (v1.z * v3.w) > (v3.z * v1.w);
+    } else if constexpr (FMT == kFmtSc8) {
+        const uint32_t w[4] = {q.v[0].x, q.v[0].y, q.v[0].z, q.v[0].w};     // two samples per word
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t a = w[j >> 1] >> (16 * (j & 1)), c = w[2 + (j >> 1)] >> (16 * (j & 1));
+            const int i0 = (int8_t)a, q0 = (int8_t)(a >> 8), i1 = (int8_t)c, q1 = (int8_t)(c >> 8);
+            b[j] = i0 * q1 > i1 * q0;
+        }
+    } else {
+        const uint32_t w[8] = {q.v[0].x, q.v[0].y, q.v[0].z, q.v[0].w, q.v[1].x, q.v[1].y, q.v[1].z, q.v[1].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float i0 = sc16_lo(w[j], 0), q0 = sc16_lo(w[j], 1), i1 = sc16_lo(w[4 + j], 0), q1 = sc16_lo(w[4 + j], 1);
+            b[j] = (i0 * q1) > (i1 * q0);
+        }
+    }
+}
+
+template <int DEPTH, int FMT>
 __global__ __launch_bounds__(256) void btle_demod_corr(
-    const float* __restrict__ iq_all, uint64_t n_samples, uint64_t iq_stride, uint32_t aa,
+    const void* __restrict__ iq_all, uint64_t n_samples, uint64_t iq_stride, uint32_t aa,
     uint32_t n_chunks, uint32_t n_slots, uint64_t* __restrict__ planes_all, uint64_t plane_stride,
     uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_hits, uint32_t cap)
 {
+    using Row = K1Row<FMT>;
+    constexpr uint32_t kBps = fmt_bytes(FMT);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (item >= n_chunks * n_slots) return;
     const uint32_t slot = item / n_chunks, chunk = item - slot * n_chunks;
-    const float* iq = iq_all + 2ull * slot * iq_stride;
+    const char* iq = reinterpret_cast<const char*>(iq_all) + (uint64_t)kBps * slot * iq_stride;
     uint64_t* planes = planes_all + (size_t)slot * plane_stride;
     uint32_t* list = chunk_hits + (size_t)item * cap;
 
@@ -96,31 +137,31 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
     const uint32_t it0 = chunk * (uint32_t)kChunkIters;       // first iteration of this chunk
     const uint32_t itw = it0 - (chunk > 0 ? 1u : 0u);         // warm-up iteration (history only)
     const uint64_t base_sample = (uint64_t)itw * kIterSamples;
-    const uint64_t rem = (n_samples - base_sample) * 8ull;
+    // (range checks are per dword: an odd number of 2-byte samples is rounded up, the half dword past
+    //  the end only reaches bit n_samples - 4, which nothing consumes)
+    const uint64_t rem = ((n_samples - base_sample) * kBps + 3u) & ~3ull;
     const uint32_t recs = rem > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rem;
     // wave-uniform descriptor; out-of-range reads return 0, so the tail needs no branches
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(iq + 2ull * base_sample), 0, (int)recs, 0x00020000);
+        (void*)(iq + (uint64_t)kBps * base_sample), 0, (int)recs, 0x00020000);
 
     uint64_t prev[4] = {0, 0, 0, 0};
     uint64_t keep[4] = {0, 0, 0, 0};
     uint32_t cnt = 0;
     const uint32_t n_it = (uint32_t)kChunkIters + (it0 - itw);
 
-    auto ld = [&](uint32_t off) -> f32x4 {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-    };
+    auto ld = [&](uint32_t off) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0); };
     // samples 4l..4l+7 of a row: (I,Q) pairs; the upper half overlaps the next lane's lower half
-    f32x4 q[DEPTH][4];
+    Row q[DEPTH];
 #pragma unroll
     for (int u = 0; u < DEPTH; u++) {
-        const uint32_t voff = (uint32_t)u * 2048u + lane * 32u;      // rows past n_it read as 0 or
-#pragma unroll                                                       // belong to the next chunk: unused
-        for (int k = 0; k < 4; k++) q[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t voff = (uint32_t)u * Row::kRowBytes + lane * Row::kLaneBytes;   // rows past n_it read as 0 or
+#pragma unroll                                                                      // belong to the next chunk: unused
+        for (uint32_t k = 0; k < Row::kLoads; k++) q[u].v[k] = u32x4{0u, 0u, 0u, 0u};
         // the warm-up row only feeds the 31-symbol history: its lower half is never looked at
         if (!(u == 0 && it0 != itw && lane < 32u)) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[u][k] = ld(voff + 16u * k);
+            for (uint32_t k = 0; k < Row::kLoads; k++) q[u].v[k] = ld(voff + 16u * k);
         }
     }
     for (uint32_t r0 = 0; r0 < n_it; r0 += DEPTH) {
@@ -128,18 +169,14 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
         for (int u = 0; u < DEPTH; u++) {
             const uint32_t r = r0 + (uint32_t)u;
             if (r >= n_it) break;
-            const f32x4 v0 = q[u][0], v1 = q[u][1], v2 = q[u][2], v3 = q[u][3];
+            const Row cur_row = q[u];
             if (r + DEPTH < n_it) {
-                const uint32_t voff = (r + DEPTH) * 2048u + lane * 32u;
+                const uint32_t voff = (r + DEPTH) * Row::kRowBytes + lane * Row::kLaneBytes;
 #pragma unroll
-                for (int k = 0; k < 4; k++) q[u][k] = ld(voff + 16u * k);
+                for (uint32_t k = 0; k < Row::kLoads; k++) q[u].v[k] = ld(voff + 16u * k);
             }
-            // bit[n] = (I[n]*Q[n+4]) > (I[n+4]*Q[n]); two roundings, no contraction
             bool b[4];
-            b[0] = (v0.x * v2.y) > (v2.x * v0.y);
-            b[1] = (v0.z * v2.w) > (v2.z * v0.w);
-            b[2] = (v1.x * v3.y) > (v3.x * v1.y);
-            b[3] = (v1.z * v3.w) > (v3.z * v1.w);
+            k1_bits<FMT>(cur_row, b);
             uint64_t cur[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) cur[j] = __ballot(b[j]);
@@ -618,20 +655,24 @@ int BtleCtx::reserve(uint64_t n)
 }
 
 // Narrowband front end: iq (device) -> planes + per-chunk hit lists.
-int BtleCtx::launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
-                                ResultSlot* timing)
+int BtleCtx::launch_demod_corr(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
+                                ResultSlot* timing, int fmt)
 {
     const uint32_t total = n_chunks * n_slots;
     if (timing) SNOUT_HIP(hipEventRecord(timing->ev_k0, st));
-#define SNOUT_K1(D)                                                                                  \
-    hipLaunchKernelGGL((btle_demod_corr<D>), dim3(cdiv(total, 4)), dim3(256), 0, st, d_iq, n, iq_stride, \
+#define SNOUT_K1(D, F)                                                                               \
+    hipLaunchKernelGGL((btle_demod_corr<D, F>), dim3(cdiv(total, 4)), dim3(256), 0, st, d_iq, n, iq_stride, \
                        aa, n_chunks, n_slots, d_planes.as<uint64_t>(), plane_stride,                  \
                        d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap)
-    switch (variant) {          // prefetch depth; SNOUT_K1_DEPTH overrides for experiments
-        case 3: SNOUT_K1(3); break;
-        case 4: SNOUT_K1(4); break;
-        case 2: SNOUT_K1(2); break;
-        default: SNOUT_K1(1); break;
+    if (fmt == kFmtSc8) {
+        SNOUT_K1(4, kFmtSc8);   // 16 B per lane and row: deeper prefetch keeps as many bytes in flight
+    } else if (fmt == kFmtSc16) {
+        SNOUT_K1(2, kFmtSc16);
+    } else switch (variant) {   // prefetch depth; SNOUT_K1_DEPTH overrides for experiments
+        case 3: SNOUT_K1(3, kFmtCf32); break;
+        case 4: SNOUT_K1(4, kFmtCf32); break;
+        case 2: SNOUT_K1(2, kFmtCf32); break;
+        default: SNOUT_K1(1, kFmtCf32); break;
     }
 #undef SNOUT_K1
     if (timing) SNOUT_HIP(hipEventRecord(timing->ev_k1, st));

@@ -67,7 +67,7 @@ struct ResultSlot {
     hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_front = nullptr,
                ev_compute = nullptr, ev_copy = nullptr;
     // bookkeeping of the submitted segment
-    const float* iq = nullptr;
+    const void* iq = nullptr;           // cf32 / sc8 / sc16 as the handle is configured (iq_fmt.h)
     uint64_t n_in = 0, first_index = 0, spec_copied = 0, n_pkts = 0;
     hipStream_t stream = nullptr;
     bool timed = false;
@@ -93,8 +93,8 @@ struct BtleCtx {
              uint32_t max_hits);
     void destroy();
     int reserve(uint64_t n_channel_samples);
-    int launch_demod_corr(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
-                          ResultSlot* timing);
+    int launch_demod_corr(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
+                          ResultSlot* timing, int fmt = 0);
     int launch_corr_planes(uint64_t n, hipStream_t st);
     // hit lists -> ordered records in s.d_out, totals in s.d_totals (no host sync)
     int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s);
@@ -128,8 +128,8 @@ struct PfbCtx {
     uint64_t n_out_for(uint64_t n) const;
     // planes16 != null (M = 40): fused BTLE mode, hard bits go straight into the bit planes
     // zbt != null (M = 16): fused 802.15.4 mode, discriminator output goes straight to the Zigbee context
-    int run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16 = nullptr,
-            uint64_t plane_stride = 0, const PfbZbTarget* zbt = nullptr);
+    int run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16 = nullptr,
+            uint64_t plane_stride = 0, const PfbZbTarget* zbt = nullptr, int fmt = 0);
 };
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
@@ -157,8 +157,8 @@ struct ZbCtx {
     // front end (discriminator, carry-in, lanes) and tail (stitch, sinks, ordered compaction into
     // s.d_out / s.d_totals); no host sync
     // d_iq == nullptr: the fused channelizer has already written d and S (see pfb_target)
-    int enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
-                      bool time_front);
+    int enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
+                      bool time_front, int fmt = 0);
     PfbZbTarget pfb_target() const;
     int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s, bool time_front);
     bool check_overflow(const ResultSlot& s);

@@ -28,6 +28,7 @@
 // columns), so MFMA does not apply; see DESIGN.md.
 #include "common.h"
 #include "zb_discrim.h"
+#include "iq_fmt.h"
 #include "pfb_tables.inc"
 
 namespace snout {
@@ -137,9 +138,10 @@ template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, N
 // (channel, phase) decides 15 symbols of the tile at once and the 16th when the next tile's first
 // outputs exist (it carries its last sample and the pending 15 bits in registers); the workgroup
 // therefore also computes the tile after its range, without emitting that tile's own bits.
-template <int M, bool FUSED>
+// FMT: input sample format (iq_fmt.h); integer samples are converted as they are fetched.
+template <int M, bool FUSED, int FMT>
 __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(SNOUT_PFB_WPE))) void pfb_channelize(
-    const float2* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
+    const void* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
     uint64_t plane_stride, PfbZbOut zb)
@@ -186,11 +188,10 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     const uint32_t t_last = (FUSED && M == 40 && t_end < n_tiles) ? t_end + 1u : t_end;
     const uint32_t t_first = (ZB && t_begin > 0u) ? t_begin - 1u : t_begin;
 
-    const float4* x4 = reinterpret_cast<const float4*>(x);
     auto load_pair = [&](uint64_t g) -> float4 {               // samples g, g+1 (g even), zero past n
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (g + 1 < n) v = x4[g >> 1];
-        else if (g < n) { const float2 a = x[g]; v.x = a.x; v.y = a.y; }
+        if (g + 1 < n) v = iq_pair<FMT>(x, g);
+        else if (g < n) { const float2 a = iq_sample<FMT>(x, g); v.x = a.x; v.y = a.y; }
         return v;
     };
     // first tile: the whole span; later tiles: the overlap comes from LDS (keep), the rest from pre
@@ -407,8 +408,8 @@ uint64_t PfbCtx::n_out_for(uint64_t n) const
     return n >= L ? (n - L) / D + 1u : 0u;
 }
 
-int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride,
-                const PfbZbTarget* zbt)
+int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride,
+                const PfbZbTarget* zbt, int fmt)
 {
     n_out = n_out_for(n);
     y_stride = (n_out + 64 + 1) & ~1ull;      // even: channel rows stay 16-byte aligned
@@ -416,20 +417,23 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
     PfbZbOut zb{};
     if (zbt) zb = PfbZbOut{zbt->d, zbt->d_stride, zbt->S, zbt->nsb, zbt->atan_tab, zbt->iir_w};
     if (n_out == 0) return 0;
+#define SNOUT_PFB_F(MM, FU, F, Y, YS, PL, PS)                                                          \
+    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(nwg), dim3(PfbGeom<MM>::NT), 0, st, d_iq, n, n_out, \
+                       n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), Y, YS, PL, PS, zb)
+#define SNOUT_PFB(MM, FU, Y, YS, PL, PS)                                                               \
+    do {                                                                                              \
+        if (fmt == kFmtSc8) SNOUT_PFB_F(MM, FU, kFmtSc8, Y, YS, PL, PS);                              \
+        else if (fmt == kFmtSc16) SNOUT_PFB_F(MM, FU, kFmtSc16, Y, YS, PL, PS);                       \
+        else SNOUT_PFB_F(MM, FU, kFmtCf32, Y, YS, PL, PS);                                            \
+    } while (0)
     // persistent workgroups (3 per CU by registers), each walks a contiguous range of tiles
     if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
         const uint32_t tpw = cdiv(n_tiles, grid_blocks), nwg = cdiv(n_tiles, tpw);
         if (planes16)
-            hipLaunchKernelGGL((pfb_channelize<40, true>), dim3(nwg), dim3(PfbGeom<40>::NT), 0, st,
-                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
-                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               (float2*)nullptr, (uint64_t)0, planes16, plane_stride, zb);
+            SNOUT_PFB(40, true, (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
-            hipLaunchKernelGGL((pfb_channelize<40, false>), dim3(nwg), dim3(PfbGeom<40>::NT), 0, st,
-                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
-                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, zb);
+            SNOUT_PFB(40, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
         // 256-thread workgroups: four per CU fit (128 VGPRs, 29 KB LDS)
@@ -440,17 +444,13 @@ int PfbCtx::run(const float* d_iq, uint64_t n, hipStream_t st, uint16_t* planes1
             const uint64_t done = (uint64_t)n_tiles * PfbGeom<16>::T;
             if (done < zbt->d_stride)
                 SNOUT_HIP(hipMemset2DAsync(zbt->d + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
-            hipLaunchKernelGGL((pfb_channelize<16, true>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st,
-                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
-                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0, zb);
+            SNOUT_PFB(16, true, (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0);
         } else {
-            hipLaunchKernelGGL((pfb_channelize<16, false>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st,
-                               (const float2*)d_iq, n, n_out, n_tiles, tpw,
-                               d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(),
-                               d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0, zb);
+            SNOUT_PFB(16, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
         }
     }
+#undef SNOUT_PFB
+#undef SNOUT_PFB_F
     SNOUT_HIP(hipGetLastError());
     return 0;
 }

@@ -121,6 +121,11 @@ struct snout_rx {
     uint64_t last_n = 0, last_nch = 0, last_pkts = 0;
 };
 
+static uint32_t sample_bytes(uint32_t fmt)
+{
+    return fmt == SNOUT_FMT_SC8 ? 2u : (fmt == SNOUT_FMT_SC16 ? 4u : 8u);
+}
+
 static BtleCtx& btle_of(snout_rx* h, const ResultSlot& s)
 {
     return s.work_set == 0 ? h->btle : (s.work_set == 1 ? h->btle2 : h->btle3);
@@ -133,7 +138,8 @@ static ZbCtx& zb_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->z
 // the next segment's front end does not wait for it.
 static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
 {
-    const float* ch_iq = s.iq;
+    const void* ch_iq = s.iq;
+    int ch_fmt = (int)h->cfg.reserved[1];          // the channelizer always emits cf32
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
     // Every event on the caller's stream is a barrier packet between consecutive front-end kernels
     // (~8 us each): the narrowband BTLE path, whose kernel is the whole front end, reuses the pair
@@ -160,7 +166,8 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         }
         SNOUT_HIP(hipEventRecord(s.ev_k0, st));
         if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
-                                bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr)) return rc;
+                                bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr, ch_fmt)) return rc;
+        ch_fmt = 0;
         SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         ch_iq = (fused_zb && n_ch >= 9u) ? nullptr : h->pfb.d_y.as<float>();
         ch_stride = h->pfb.y_stride;
@@ -171,7 +178,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         if (fused) {
             if (int rc = b.launch_corr_planes(n_ch, st)) return rc;       // bits are already in the planes
         } else {
-            if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s)) return rc;
+            if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s, ch_fmt)) return rc;
         }
         if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_front, st));
         SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, nb_btle ? s.ev_k1 : s.ev_front, 0));
@@ -182,7 +189,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     } else {
         ZbCtx& z = zb_of(h, s);
         if (int rc = z.reserve(n_ch)) return rc;
-        if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide)) return rc;
+        if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
         SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, s.ev_front, 0));
         if (int rc = z.enqueue_tail(n_ch, s.first_index, h->tail_stream, s, !h->wide)) return rc;
@@ -296,6 +303,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     if (c.zb_warmup == 0) c.zb_warmup = 512;
     if (c.n_channels == 0) c.n_channels = 1;
     int rc = SNOUT_EINVAL;
+    if (c.reserved[1] > SNOUT_FMT_SC16) { set_last_error("sample format %u", c.reserved[1]); goto fail; }
     if (c.proto == SNOUT_PROTO_ZIGBEE &&
         (c.zb_core < 1024 || c.zb_core > (1u << 24) || c.zb_warmup > (1u << 20))) {
         set_last_error("zb_core %u / zb_warmup %u out of range", c.zb_core, c.zb_warmup);
@@ -391,7 +399,7 @@ void snout_rx_destroy(snout_rx* h)
     delete h;
 }
 
-static int check_segment(snout_rx* h, const float* iq_dev, uint64_t n_samples)
+static int check_segment(snout_rx* h, const void* iq_dev, uint64_t n_samples)
 {
     if (!h || (!iq_dev && n_samples)) return SNOUT_EINVAL;
     if (n_samples >= 0xFFFF0000ull) {
@@ -408,7 +416,7 @@ static bool too_short(snout_rx* h, uint64_t n_samples)
     return n_ch < (h->cfg.proto == SNOUT_PROTO_BTLE ? 5u : 9u);
 }
 
-int snout_rx_submit_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
+int snout_rx_submit_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
                         uint64_t first_sample_index, void* hip_stream)
 {
     if (int rc = check_segment(h, iq_dev, n_samples)) return rc;
@@ -429,7 +437,9 @@ int snout_rx_submit_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
         // nothing to demodulate; still channelize so the soft tap of a wideband handle is defined
         if (h->wide) {
             h->pfb.n_out = 0;
-            if (n_samples) { if (int rc = h->pfb.run(iq_dev, n_samples, s.stream)) return rc; }
+            if (n_samples) {
+                if (int rc = h->pfb.run(iq_dev, n_samples, s.stream, nullptr, 0, nullptr, (int)h->cfg.reserved[1])) return rc;
+            }
         }
         s.h_totals[0] = s.h_totals[1] = s.h_totals[2] = 0;
         s.spec_copied = 0;
@@ -506,7 +516,7 @@ int snout_rx_collect(snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out)
     return SNOUT_OK;
 }
 
-int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
+int snout_rx_process_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
                          uint64_t first_sample_index, void* hip_stream, snout_pkt* out, uint64_t cap,
                          uint64_t* n_out)
 {
@@ -542,17 +552,18 @@ int snout_rx_process_dev(snout_rx* h, const float* iq_dev, uint64_t n_samples,
     return rc;
 }
 
-int snout_rx_process(snout_rx* h, const float* iq_host, uint64_t n_samples,
+int snout_rx_process(snout_rx* h, const void* iq_host, uint64_t n_samples,
                      uint64_t first_sample_index, snout_pkt* out, uint64_t cap, uint64_t* n_out)
 {
     if (!h || !n_out || (!iq_host && n_samples)) return SNOUT_EINVAL;
     *n_out = 0;
     SNOUT_HIP(hipSetDevice(h->device));
     if (n_samples) {
-        if (int rc = h->d_iq.ensure(n_samples * 8u)) return rc;
-        SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, n_samples * 8u, hipMemcpyHostToDevice));
+        const uint64_t bytes = n_samples * sample_bytes(h->cfg.reserved[1]);
+        if (int rc = h->d_iq.ensure(bytes)) return rc;
+        SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, bytes, hipMemcpyHostToDevice));
     }
-    return snout_rx_process_dev(h, n_samples ? h->d_iq.as<float>() : nullptr, n_samples,
+    return snout_rx_process_dev(h, n_samples ? h->d_iq.p : nullptr, n_samples,
                                 first_sample_index, nullptr, out, cap, n_out);
 }
 
@@ -581,7 +592,7 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;     // see enqueue_segment
     SNOUT_HIP(hipEventElapsedTime(&out->ms_total, nb_btle ? h->hist_k0[s.hist_idx] : s.ev_t0, s.ev_copy));
     SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->hist_k0[s.hist_idx], h->hist_k1[s.hist_idx]));
-    out->bytes_algorithmic = 8ull * h->last_n + 160ull * h->last_pkts;
+    out->bytes_algorithmic = (uint64_t)sample_bytes(h->cfg.reserved[1]) * h->last_n + 160ull * h->last_pkts;
     out->n_hits = s.h_totals[0];
     out->dominant_launches = 1;
     if (h->wide) {

@@ -21,6 +21,7 @@
 #include <type_traits>
 #include "common.h"
 #include "zb_discrim.h"
+#include "iq_fmt.h"
 
 namespace snout {
 
@@ -52,7 +53,8 @@ __device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t
 // zero-state response of the single-pole IIR to its samples (double, fixed order), from which
 // zb_iir_fold / zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the
 // oracle): four threads per sub-block sum 16 terms each in sequence, S = (P0 + P1) + (P2 + P3).
-__global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq, uint64_t n,
+template <int FMT>
+__global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, uint64_t n,
                                                   uint64_t iq_stride, uint64_t d_stride, uint64_t nsb,
                                                   const float* __restrict__ atan_tab,
                                                   const double* __restrict__ iir_w,
@@ -65,20 +67,17 @@ __global__ __launch_bounds__(256) void zb_discrim(const float2* __restrict__ iq,
     if (threadIdx.x < 64) wts[threadIdx.x] = iir_w[threadIdx.x];
     __syncthreads();
     const uint32_t slot = blockIdx.y;
-    const float2* x = iq + (uint64_t)slot * iq_stride;
+    const char* x = reinterpret_cast<const char*>(iq) + (uint64_t)fmt_bytes(FMT) * slot * iq_stride;
     const uint64_t t0 = (uint64_t)blockIdx.x * 1024u + 4u * threadIdx.x;      // this thread's 4 samples
     float ang[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (t0 < n) {
         float2 xs[5];
-        xs[0] = t0 ? x[t0 - 1u] : make_float2(0.0f, 0.0f);
+        xs[0] = t0 ? iq_sample<FMT>(x, t0 - 1u) : make_float2(0.0f, 0.0f);
         if (t0 + 3u < n) {
-            const float4 a = *reinterpret_cast<const float4*>(&x[t0]);
-            const float4 b = *reinterpret_cast<const float4*>(&x[t0 + 2u]);
-            xs[1] = make_float2(a.x, a.y); xs[2] = make_float2(a.z, a.w);
-            xs[3] = make_float2(b.x, b.y); xs[4] = make_float2(b.z, b.w);
+            iq_quad<FMT>(x, t0, &xs[1]);
         } else {
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) xs[1 + k] = t0 + k < n ? x[t0 + k] : make_float2(0.0f, 0.0f);
+            for (uint32_t k = 0; k < 4u; k++) xs[1 + k] = t0 + k < n ? iq_sample<FMT>(x, t0 + k) : make_float2(0.0f, 0.0f);
         }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) {
@@ -1116,15 +1115,20 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
 
 // Front end (a4-a6) on the caller's stream: discriminator tiles, IIR carry-in, lanes.
 // iq: [n_slots][iq_stride] complex samples at 4 Msps per channel, device memory.  No host sync.
-int ZbCtx::enqueue_front(const float* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
-                         ResultSlot& s, bool time_front)
+int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
+                         ResultSlot& s, bool time_front, int fmt)
 {
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
     if (n < 9u) return 0;   // no interpolator window fits: nothing to launch
     if (d_iq) {             // otherwise the fused channelizer has already written d and S
-        hipLaunchKernelGGL(zb_discrim, dim3(cdiv(d_stride, 1024), n_slots), dim3(256), 0, st, (const float2*)d_iq, n,
-                           iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(),
-                           d_S.as<double>());
+#define SNOUT_ZBD(F)                                                                                  \
+    hipLaunchKernelGGL(zb_discrim<F>, dim3(cdiv(d_stride, 1024), n_slots), dim3(256), 0, st, d_iq, n, \
+                       iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(), \
+                       d_S.as<double>())
+        if (fmt == kFmtSc8) SNOUT_ZBD(kFmtSc8);
+        else if (fmt == kFmtSc16) SNOUT_ZBD(kFmtSc16);
+        else SNOUT_ZBD(kFmtCf32);
+#undef SNOUT_ZBD
     }
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());

@@ -21,6 +21,10 @@ class Profile:
     dominant_name: str
 
 
+FMT_CF32, FMT_SC8, FMT_SC16 = 0, 1, 2
+_NP_DTYPE = {FMT_CF32: np.float32, FMT_SC8: np.int8, FMT_SC16: np.int16}
+
+
 class SnoutRx:
     """``SnoutRx(proto, channel=37)`` -> ``process(iq)`` returns a numpy record array
     (dtype :data:`PKT_DTYPE`). ``iq`` may be a numpy complex64/float32 array (host path,
@@ -29,7 +33,8 @@ class SnoutRx:
     def __init__(self, proto: int = PROTO_BTLE, channel: int = 37, n_channels: int = 1,
                  access_addr: int = 0, crc_init: int = 0, chip_threshold: int = 0,
                  taps_per_branch: int = 0, zb_core: int = 0, zb_warmup: int = 0,
-                 max_hits: int = 0, device: int = -1, keep_channel_iq: bool = False):
+                 max_hits: int = 0, device: int = -1, keep_channel_iq: bool = False,
+                 sample_format: int = 0):
         self._lib = _ffi.load()
         cfg = _ffi.RxCfg(abi_version=_ffi.ABI_VERSION, proto=proto, n_channels=n_channels,
                          taps_per_branch=taps_per_branch, channel=channel,
@@ -37,6 +42,8 @@ class SnoutRx:
                          chip_threshold=chip_threshold, zb_core=zb_core, zb_warmup=zb_warmup,
                          max_hits=max_hits, device=device)
         cfg.reserved[0] = 1 if keep_channel_iq else 0      # unfused wideband BTLE (CHAN_IQ tap)
+        cfg.reserved[1] = int(sample_format)               # FMT_CF32 / FMT_SC8 / FMT_SC16
+        self.sample_format = int(sample_format)
         self._h = C.c_void_p()
         _ffi.check(self._lib.snout_rx_create(C.byref(cfg), C.byref(self._h)))
         self.proto = proto
@@ -94,8 +101,9 @@ class SnoutRx:
             a = np.ascontiguousarray(iq)
             if a.dtype == np.complex64:
                 a = a.view(np.float32)
-            if a.dtype != np.float32:
-                raise TypeError("iq must be complex64 or interleaved float32")
+            if a.dtype != _NP_DTYPE[self.sample_format]:
+                raise TypeError(f"iq must be interleaved {_NP_DTYPE[self.sample_format].__name__} "
+                                "(complex64 for cf32) for this handle's sample format")
             n = a.size // 2
             return self._run(lambda *r: self._lib.snout_rx_process(
                 self._h, a.ctypes.data_as(C.c_void_p), n, first_sample_index, *r),
@@ -104,16 +112,21 @@ class SnoutRx:
         import torch
         if not (isinstance(iq, torch.Tensor) and iq.is_cuda and iq.is_contiguous()):
             raise TypeError("iq must be a numpy array or a contiguous torch CUDA tensor")
-        if iq.dtype == torch.complex64:
-            n = iq.numel()
-        elif iq.dtype == torch.float32:
-            n = iq.numel() // 2
-        else:
-            raise TypeError("iq tensor must be complex64 or float32")
+        n = self._tensor_samples(iq)
         st = stream if stream is not None else torch.cuda.current_stream(iq.device).cuda_stream
         return self._run(lambda *r: self._lib.snout_rx_process_dev(
             self._h, C.c_void_p(iq.data_ptr()), n, first_sample_index, C.c_void_p(st), *r),
             cap=max(4096, n // 2048), copy=copy)
+
+    def _tensor_samples(self, iq) -> int:
+        """Complex samples in a device tensor of this handle's sample format."""
+        import torch
+        want = {0: torch.float32, 1: torch.int8, 2: torch.int16}[self.sample_format]
+        if self.sample_format == 0 and iq.dtype == torch.complex64:
+            return iq.numel()
+        if iq.dtype != want:
+            raise TypeError(f"iq tensor must be interleaved {want} for this handle's sample format")
+        return iq.numel() // 2
 
     # ---- pipelined form: up to three segments in flight ---------------------------------------
     def submit(self, iq, first_sample_index: int = 0, stream: Optional[int] = None) -> None:
@@ -122,7 +135,7 @@ class SnoutRx:
         import torch
         if not (isinstance(iq, torch.Tensor) and iq.is_cuda and iq.is_contiguous()):
             raise TypeError("submit() needs a contiguous torch CUDA tensor")
-        n = iq.numel() if iq.dtype == torch.complex64 else iq.numel() // 2
+        n = self._tensor_samples(iq)
         st = stream if stream is not None else torch.cuda.current_stream(iq.device).cuda_stream
         _ffi.check(self._lib.snout_rx_submit_dev(self._h, C.c_void_p(iq.data_ptr()), n,
                                                  first_sample_index, C.c_void_p(st)))

@@ -332,3 +332,15 @@ def wideband_capture(proto: int, n_samples: int, seed: int = 3, bins: Optional[S
         x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
               ).astype(np.complex64)
     return x, truth
+
+
+def quantize(x: np.ndarray, sample_format: int, full_scale: float = 0.0) -> np.ndarray:
+    """Complex capture -> interleaved int8 (sample_format 1, HackRF) or int16 (2, USRP sc16) as an
+    SDR's ADC path would deliver it: scaled so that ``full_scale`` (default: 1.25 x the largest
+    component) maps to the integer range, rounded to nearest, clipped."""
+    a = to_interleaved(x)
+    bits = {1: 7, 2: 15}[sample_format]
+    fs = full_scale or 1.25 * float(np.max(np.abs(a))) or 1.0
+    q = np.rint(a * ((1 << bits) / fs))
+    lim = (1 << bits) - 1
+    return np.clip(q, -lim - 1, lim).astype(np.int8 if sample_format == 1 else np.int16)

@@ -1,0 +1,111 @@
+"""GPU parity: integer input sample formats (include/snout_rx.h SNOUT_FMT_SC8 / SC16).
+
+An sc8 / sc16 capture stands for the cf32 capture v * 2^-7 / v * 2^-15 (exact in float32), so the
+check is: records from the integer capture through the C ABI == the CPU oracle on the converted
+capture, bit for bit, on all four receive paths, from host and from device memory, for ragged
+lengths and the integer extremes (-128 / -32768)."""
+import numpy as np
+import pytest
+
+from snout_amd import synth
+from snout_amd._ffi import STAGE_BTLE_BITS, STAGE_CHAN_IQ, STAGE_ZB_DISCRIM
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags", "aux")
+
+
+def _same(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for f in FIELDS:
+        assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(a["bytes"], b["bytes"])
+
+
+def _rx(**kw):
+    from snout_amd.rx import SnoutRx
+    return SnoutRx(**kw)
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("n,seed", [(1 << 18, 31), ((1 << 17) + 1234, 32), (16384 * 3 + 5, 33)])
+def test_btle_narrowband(oracle, fmt, n, seed):
+    import torch
+    x, truth = synth.btle_capture(n, channel=37, seed=seed, mean_gap=6000.0)
+    q = synth.quantize(x, fmt)
+    want, hits = oracle.btle_segment(oracle.from_int(q), channel=37, first_sample_index=99)
+    with _rx(proto=0, channel=37, sample_format=fmt) as rx:
+        got = rx.process(q, first_sample_index=99)                       # host input
+        _same(got, want)
+        bits = rx.soft(STAGE_BTLE_BITS, 0).astype(np.uint8)
+        assert np.array_equal(bits, oracle.btle_bits(oracle.from_int(q)))
+        got_d = rx.process(torch.from_numpy(q).cuda(), first_sample_index=99)   # device input
+        _same(got_d, want)
+    ok = {bytes(p["bytes"][:p["len"] - 3]) for p in got if p["crc_ok"]}
+    assert sum(t.payload in ok for t in truth) >= len(truth) - 1 and len(truth) > 3
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_btle_integer_extremes_and_noise(oracle, fmt):
+    """Uniform random integers over the whole range, including -128 / -32768 (whose negation does
+    not exist) and runs of zeros: every hard bit equals the oracle's."""
+    rng = np.random.default_rng(5 + fmt)
+    info = np.iinfo(np.int8 if fmt == 1 else np.int16)
+    q = rng.integers(info.min, info.max + 1, size=2 * 70001, dtype=info.dtype)
+    q[1000:3000] = 0
+    q[5000:5064] = info.min
+    q[7000:7064:2] = info.min
+    q[7001:7064:2] = info.max
+    with _rx(proto=0, channel=12, sample_format=fmt) as rx:
+        got = rx.process(q)
+        bits = rx.soft(STAGE_BTLE_BITS, 0).astype(np.uint8)
+    f = oracle.from_int(q)
+    assert np.array_equal(bits, oracle.btle_bits(f))
+    _same(got, oracle.btle_segment(f, channel=12)[0])
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("n,seed", [(1 << 18, 41), ((1 << 17) + 777, 42)])
+def test_zigbee_narrowband(oracle, fmt, n, seed):
+    import torch
+    x, truth = synth.zigbee_capture(n, channel=15, seed=seed, mean_gap=9000.0)
+    q = synth.quantize(x, fmt)
+    f = oracle.from_int(q)
+    want = oracle.zigbee_segment(f, channel=15, first_sample_index=7)
+    with _rx(proto=1, channel=15, sample_format=fmt) as rx:
+        got = rx.process(q, first_sample_index=7)
+        _same(got, want)
+        d = rx.soft(STAGE_ZB_DISCRIM, 0)
+        assert np.array_equal(d, oracle.zb_discrim(f))      # same operations in the same order
+        _same(rx.process(torch.from_numpy(q).cuda(), first_sample_index=7), want)
+    ok = {bytes(p["bytes"][:p["len"]]) for p in got if p["crc_ok"]}
+    assert sum(t.payload in ok for t in truth) >= 0.9 * len(truth) and len(truth) > 3
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("proto,M,n", [(0, 40, 40 * 30000 + 13), (1, 16, 16 * 70000 + 5)])
+def test_wideband(oracle, fmt, proto, M, n):
+    bins = [3, 17, 28] if proto == 0 else [2, 9]
+    x, truth = synth.wideband_capture(proto, n, seed=50 + fmt, bins=bins, mean_gap=5000.0)
+    q = synth.quantize(x, fmt)
+    f = oracle.from_int(q)
+    want = oracle.wideband_segment(f, proto=proto)
+    with _rx(proto=proto, n_channels=M, sample_format=fmt) as rx:        # fused kernels
+        _same(rx.process(q), want)
+    with _rx(proto=proto, n_channels=M, sample_format=fmt, keep_channel_iq=True) as rx:
+        _same(rx.process(q), want)
+        y = oracle.pfb(f, M)
+        for slot in (bins[0], M - 1):
+            got_y = rx.soft(STAGE_CHAN_IQ, slot).view(np.complex64)
+            assert np.array_equal(got_y, y[slot])
+    ok = sum(1 for p in want if p["crc_ok"])
+    assert ok >= 0.8 * len(truth) and len(truth) > 5
+
+
+def test_wrong_dtype_is_refused():
+    with _rx(proto=0, channel=37, sample_format=1) as rx:
+        with pytest.raises(TypeError):
+            rx.process(np.zeros(1024, dtype=np.float32))
+    from snout_amd._ffi import SnoutError
+    with pytest.raises(SnoutError):
+        _rx(proto=0, channel=37, sample_format=3)
