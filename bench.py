@@ -112,6 +112,8 @@ def cpu_baseline(x_dev, n_sample: int, passes: int, workload: str = "cfg2"):
     from oracle import oracle_py
     oracle_py.lib()
     host = x_dev[:2 * n_sample].cpu().numpy()
+    if host.dtype != np.float32:
+        host = oracle_py.from_int(host)     # the oracle's definition of integer input (untimed)
     best = None
     n_pk = 0
     for _ in range(passes):
@@ -136,6 +138,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--samples", type=float, default=0,
                     help="complex input samples per GPU per step (default: the workload's size)")
+    ap.add_argument("--format", choices=["cf32", "sc8", "sc16"], default="cf32",
+                    help="input sample format resident in HBM (cf32 is BASELINE's; sc8 = HackRF / upstream "
+                         "btle_rx int8 IQ, sc16 = USRP): the same capture quantised on the device")
     ap.add_argument("--cpu-samples", type=float, default=0,
                     help="samples of the CPU baseline leg (default: ~10-30 s of oracle time)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -171,7 +176,19 @@ def main():
     proto, n_ch, channel, n_default, rec_width, metric, descr = WORKLOADS[args.workload]
     n = int(args.samples or n_default)
     x, expect, pdus = make_workload(n, seed=2 + rank, device=device, workload=args.workload)
-    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=local_rank)
+    fmt = {"cf32": 0, "sc8": 1, "sc16": 2}[args.format]
+    if fmt:
+        # what the SDR's ADC path would have delivered: full scale = 1.25 x the largest component
+        bits = 7 if fmt == 1 else 15
+        scale = float(1 << bits) / (1.25 * float(x.abs().max()))
+        xi = torch.empty(x.shape, dtype=torch.int8 if fmt == 1 else torch.int16, device=device)
+        step = 1 << 26
+        for lo in range(0, x.numel(), step):
+            xi[lo:lo + step] = (x[lo:lo + step] * scale).round_().clamp_(-(1 << bits), (1 << bits) - 1)
+        x = xi
+        del xi
+        torch.cuda.empty_cache()
+    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=local_rank, sample_format=fmt)
 
     # Pipelined steps: up to three segments are in flight, so the next front-end kernel is already
     # queued when the previous one ends and the record D2H (copy stream) overlaps compute.  Every step's records are
@@ -248,13 +265,13 @@ def main():
     if rank == 0:
         total_samples = n * world * args.steps
         k_avg_ms = float(np.mean(k_ms))
-        algo_bytes = 8.0 * n + 160.0 * len(local)
+        algo_bytes = float(x.element_size() * 2) * n + 160.0 * len(local)
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tpath):       # PMC-derived HBM bytes per launch of the same workload
             tj = json.load(open(tpath))
-            if (args.workload == "cfg2" and tj.get("workload_samples") == n
+            if (args.workload == "cfg2" and fmt == 0 and tj.get("workload_samples") == n
                     and tj.get("kernel") == prof.dominant_name):
                 traffic = tj["traffic_bytes_per_launch"]
         out = {
@@ -268,9 +285,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if fmt == 0 else ("i8->i32" if (fmt == 1 and args.workload == "cfg2") else
+                                             args.format + "->f32"),
             "data": "synthetic",
-            "config": {"workload": "%s, %.3g cf32 samples per GPU resident in HBM" % (descr, n),
+            "config": {"workload": "%s, %.3g %s samples per GPU resident in HBM" % (descr, n, args.format),
                        "samples_per_gpu": n, "packets_per_gpu": int(len(local)),
                        "decoded_pkts_per_s": len(local) * world * args.steps / dt,
                        "sharding": "segments per rank, RCCL gather of 160-B records" if world > 1

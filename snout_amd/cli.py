@@ -40,9 +40,12 @@ def main():
     """MI355X-native receive path behind Snout's scan interface."""
 
 
-def _source(proto, iq, synthetic, channels, seconds):
+FORMATS = {"cf32": 0, "sc8": 1, "sc16": 2}
+
+
+def _source(proto, iq, synthetic, channels, seconds, fmt="cf32"):
     if iq:
-        return FileSource(iq)
+        return FileSource(iq, FORMATS[fmt])
     if not synthetic:
         raise click.UsageError("give --iq FILE or --synthetic (no live SDR in this build)")
     n = int(seconds * 4e6)
@@ -56,7 +59,9 @@ def _scan_options(f):
         click.option("-n", "--packets", type=int, default=None, help="stop after N packets"),
         click.option("-t", "--timeout", type=float, default=None, help="seconds of capture per channel"),
         click.option("-f", "--filename", default=None, help="dump file"),
-        click.option("--iq", type=click.Path(exists=True), default=None, help="cf32 capture file"),
+        click.option("--iq", type=click.Path(exists=True), default=None, help="capture file"),
+        click.option("--format", "fmt", type=click.Choice(sorted(FORMATS)), default="cf32",
+                     help="sample format of --iq: cf32, sc8 (hackrf_transfer int8), sc16"),
         click.option("--synthetic", is_flag=True, help="generate a synthetic capture"),
         click.option("--seconds", type=float, default=0.25, help="length of a synthetic capture"),
     ]):
@@ -72,9 +77,9 @@ def btle():
 @btle.command("scan")
 @_scan_options
 @click.option("--summary", is_flag=True, help="print the device table at the end (snout/util/btle.py:202-240)")
-def btle_scan(channels, packets, timeout, filename, iq, synthetic, seconds, summary):
+def btle_scan(channels, packets, timeout, filename, iq, fmt, synthetic, seconds, summary):
     chs = parse_channels(channels or DEFAULTS["btle"]["default"], "btle")
-    scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds),
+    scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds, fmt),
                     timeout=timeout, packet_threshold=packets, filename=filename)
     scan.events.on("btle.packet-received",
                    lambda message: click.echo(message.raw.decode().rstrip("\n")))
@@ -93,9 +98,9 @@ def zigbee():
 @zigbee.command("scan")
 @_scan_options
 @click.option("--udp", is_flag=True, help="send RFtap datagrams to 127.0.0.1:52002 (scapy-radio)")
-def zigbee_scan(channels, packets, timeout, filename, iq, synthetic, seconds, udp):
+def zigbee_scan(channels, packets, timeout, filename, iq, fmt, synthetic, seconds, udp):
     chs = parse_channels(channels or DEFAULTS["zigbee"]["default"], "zigbee")
-    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds),
+    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds, fmt),
                       timeout=timeout, packet_threshold=packets, udp=udp)
     def show(message):
         from .formats import parse_mhr
@@ -120,9 +125,10 @@ def zigbee_scan(channels, packets, timeout, filename, iq, synthetic, seconds, ud
 @click.option("-a", "access", default="8e89bed6")
 @click.option("-k", "crcinit", default="555555")
 @click.option("--iq", type=click.Path(exists=True), required=True)
-def btle_rx(channel, gain, access, crcinit, iq):
+@click.option("--format", "fmt", type=click.Choice(sorted(FORMATS)), default="cf32")
+def btle_rx(channel, gain, access, crcinit, iq, fmt):
     """Drop-in for the `btle_rx` child: same argv (snout/util/btle.py:63-68), same stdout lines."""
-    scan = BtleScan(channels=[channel], source=FileSource(iq), timeout=None,
+    scan = BtleScan(channels=[channel], source=FileSource(iq, FORMATS[fmt]), timeout=None,
                     access_addr=int(access, 16), crc_init=int(crcinit, 16))
     for line in scan.lines(channel):
         sys.stdout.write(line.decode())

@@ -58,6 +58,45 @@ __device__ __forceinline__ float4 iq_pair(const void* __restrict__ base, uint64_
     }
 }
 
+// The same pair kept raw (as loaded) and converted later: lets a kernel issue the load early and pay
+// the conversion where the data is consumed.
+template <int FMT> struct IqRaw { using pair = float4; };
+template <> struct IqRaw<kFmtSc8> { using pair = uint32_t; };
+template <> struct IqRaw<kFmtSc16> { using pair = uint2; };
+
+template <int FMT>
+__device__ __forceinline__ typename IqRaw<FMT>::pair iq_pair_raw(const void* __restrict__ base, uint64_t i)
+{
+    return reinterpret_cast<const typename IqRaw<FMT>::pair*>(base)[i >> 1];
+}
+
+// sample i alone in the low half of a raw pair, the other half zero
+template <int FMT>
+__device__ __forceinline__ typename IqRaw<FMT>::pair iq_single_raw(const void* __restrict__ base, uint64_t i)
+{
+    if constexpr (FMT == kFmtSc8) {
+        return (uint32_t)reinterpret_cast<const uint16_t*>(base)[i];
+    } else if constexpr (FMT == kFmtSc16) {
+        return make_uint2(reinterpret_cast<const uint32_t*>(base)[i], 0u);
+    } else {
+        const float2 a = reinterpret_cast<const float2*>(base)[i];
+        return make_float4(a.x, a.y, 0.0f, 0.0f);
+    }
+}
+
+template <int FMT>
+__device__ __forceinline__ float4 iq_pair_cvt(typename IqRaw<FMT>::pair w)
+{
+    constexpr float s = fmt_scale(FMT);
+    if constexpr (FMT == kFmtSc8) {
+        return make_float4(sc8_lo(w, 0) * s, sc8_lo(w, 1) * s, sc8_lo(w, 2) * s, sc8_lo(w, 3) * s);
+    } else if constexpr (FMT == kFmtSc16) {
+        return make_float4(sc16_lo(w.x, 0) * s, sc16_lo(w.x, 1) * s, sc16_lo(w.y, 0) * s, sc16_lo(w.y, 1) * s);
+    } else {
+        return w;
+    }
+}
+
 // samples i .. i+3 (i a multiple of 4)
 template <int FMT>
 __device__ __forceinline__ void iq_quad(const void* __restrict__ base, uint64_t i, float2 out[4])

@@ -188,17 +188,21 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     const uint32_t t_last = (FUSED && M == 40 && t_end < n_tiles) ? t_end + 1u : t_end;
     const uint32_t t_first = (ZB && t_begin > 0u) ? t_begin - 1u : t_begin;
 
-    auto load_pair = [&](uint64_t g) -> float4 {               // samples g, g+1 (g even), zero past n
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (g + 1 < n) v = iq_pair<FMT>(x, g);
-        else if (g < n) { const float2 a = iq_sample<FMT>(x, g); v.x = a.x; v.y = a.y; }
+    // Samples are fetched one tile ahead and stay RAW in registers until they are staged: converting
+    // an integer format right behind the load would make the FIR wait for the load.
+    using Raw = typename IqRaw<FMT>::pair;
+    auto load_pair = [&](uint64_t g) -> Raw {                  // samples g, g+1 (g even), zero past n
+        if (g + 1 < n) return iq_pair_raw<FMT>(x, g);
+        Raw v = Raw{};
+        if (g < n) v = iq_single_raw<FMT>(x, g);
         return v;
     };
     // first tile: the whole span; later tiles: the overlap comes from LDS (keep), the rest from pre
-    float4 keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pre[NPRE];
+    float4 keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    Raw pre[NPRE];
     {
         const uint64_t in0 = (uint64_t)t_first * NEW;            // even -> 16-byte aligned
-        if (t < OV4) keep = load_pair(in0 + 2ull * (uint64_t)t);
+        if (t < OV4) keep = iq_pair_cvt<FMT>(load_pair(in0 + 2ull * (uint64_t)t));
 #pragma unroll
         for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in0 + 2ull * (uint64_t)(OV4 + t + k * NT));
     }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         // ---- 1. stage: overlap to the front, new samples behind it
         if (t < OV4) reinterpret_cast<float4*>(xs)[t] = keep;
 #pragma unroll
-        for (int k = 0; k < NPRE; k++) reinterpret_cast<float4*>(xs)[OV4 + t + k * NT] = pre[k];
+        for (int k = 0; k < NPRE; k++) reinterpret_cast<float4*>(xs)[OV4 + t + k * NT] = iq_pair_cvt<FMT>(pre[k]);
         lds_barrier();
         if (tile + 1u < t_last) {
             const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile

@@ -35,13 +35,20 @@ class IqSource:
 
 
 class FileSource(IqSource):
-    """cf32 file (GNU Radio file_sink format) holding one channel."""
+    """Capture file holding one channel: cf32 (GNU Radio file_sink format, sample_format 0), or
+    interleaved int8 (1: `hackrf_transfer -r`, the input of upstream btle_rx) / int16 (2: USRP
+    sc16) — integer captures go to the GPU as they are, read back as an [n, 2] array so that
+    indexing is by sample."""
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, sample_format: int = 0):
         self.path = path
+        self.sample_format = int(sample_format)
 
     def read(self, channel: int) -> np.ndarray:
-        return np.fromfile(self.path, dtype=np.complex64)
+        if self.sample_format == 0:
+            return np.fromfile(self.path, dtype=np.complex64)
+        a = np.fromfile(self.path, dtype=np.int8 if self.sample_format == 1 else np.int16)
+        return a[:a.size // 2 * 2].reshape(-1, 2)
 
 
 class ArraySource(IqSource):
@@ -93,7 +100,8 @@ class BtleScan:
         alike, in capture order — what the reference reads from the child's stdout."""
         x = self.source.read(channel)
         with SnoutRx(proto=_ffi.PROTO_BTLE, channel=channel, access_addr=self.access_addr,
-                     crc_init=self.crc_init, device=self.device) as rx:
+                     crc_init=self.crc_init, device=self.device,
+                     sample_format=getattr(self.source, "sample_format", 0)) as rx:
             start = 0
             seen_until = -1
             while start < len(x):
@@ -166,7 +174,8 @@ class ZigbeeScan:
 
     def frames(self, channel: int):
         x = self.source.read(channel)
-        with SnoutRx(proto=_ffi.PROTO_ZIGBEE, channel=channel, device=self.device) as rx:
+        with SnoutRx(proto=_ffi.PROTO_ZIGBEE, channel=channel, device=self.device,
+                     sample_format=getattr(self.source, "sample_format", 0)) as rx:
             start = 0
             recent = []                     # (sample_index, bytes) of frames near the segment seam
             while start < len(x):

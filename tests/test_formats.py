@@ -88,3 +88,25 @@ def test_rftap_datagram_layout():
     assert (len32, flags, dlt) == (4, 0x0081, 195)
     assert struct.unpack("<f", d[12:16])[0] == np.float32(204) / np.float32(255)
     assert d[16:] == mpdu and len(d) == 4 * len32 + len(mpdu)
+
+
+def test_integer_sample_formats_are_exact_in_float32():
+    """include/snout_rx.h: an sc8 / sc16 sample v stands for v * 2^-7 / v * 2^-15.  Both the conversion
+    and the scale are exact in float32, so the integer paths can be checked bit for bit against the
+    cf32 oracle on the converted capture."""
+    import numpy as np
+    from oracle import oracle_py
+    from snout_amd import synth
+    for dt, bits in ((np.int8, 7), (np.int16, 15)):
+        info = np.iinfo(dt)
+        v = np.arange(info.min, info.max + 1, dtype=dt)
+        f = oracle_py.from_int(v)
+        assert f.dtype == np.float32
+        assert np.array_equal(f.astype(np.float64) * 2.0 ** bits, v.astype(np.float64))
+    x = (np.linspace(-1, 1, 4001) + 1j * np.linspace(1, -1, 4001)).astype(np.complex64)
+    for fmt, dt in ((1, np.int8), (2, np.int16)):
+        q = synth.quantize(x, fmt)
+        assert q.dtype == dt and q.size == 2 * x.size
+        assert q.max() <= np.iinfo(dt).max * 0.81 and q.min() >= np.iinfo(dt).min * 0.81   # 1.25x headroom
+        err = np.abs(oracle_py.from_int(q) * 1.25 - x.view(np.float32))
+        assert err.max() <= 1.25 * 2.0 ** -(7 if fmt == 1 else 15) * 0.5 + 1e-7

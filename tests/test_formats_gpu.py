@@ -109,3 +109,43 @@ def test_wrong_dtype_is_refused():
     from snout_amd._ffi import SnoutError
     with pytest.raises(SnoutError):
         _rx(proto=0, channel=37, sample_format=3)
+
+
+def test_hackrf_style_file_through_the_btle_rx_child(tmp_path):
+    """The cfg #1 recording re-quantised to int8 IQ (what `hackrf_transfer -r` writes and upstream
+    btle_rx consumes): `snout_amd.cli btle-rx --format sc8` prints the same 8 lines' fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from snout_amd.message import BtleMessage
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    x = np.fromfile(os.path.join(gold, "btle_ch37_4msps.cf32"), dtype=np.complex64)
+    path = tmp_path / "btle_ch37.sc8"
+    synth.quantize(x, 1).tofile(path)
+    out = subprocess.run([sys.executable, "-m", "snout_amd.cli", "btle-rx", "-c", "37", "-g", "6",
+                          "-a", "8e89bed6", "-k", "555555", "--iq", str(path), "--format", "sc8"],
+                         cwd=root, capture_output=True, timeout=300, check=True)
+    msgs = [m for m in (BtleMessage.fromraw(ln) for ln in out.stdout.splitlines(keepends=True)) if m]
+    truth = json.load(open(os.path.join(gold, "btle_ch37_truth.json")))
+    assert len(msgs) == 8
+    for m, t in zip(msgs, truth):
+        pdu = bytes.fromhex(t["pdu"])
+        assert m.sender == pdu[2:8][::-1].hex() and m.payload_hex == pdu[8:].hex()
+
+
+def test_sc16_file_through_zigbee_scan(tmp_path):
+    import json
+    import os
+    from snout_amd.scan import FileSource, ZigbeeScan
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    x = np.fromfile(os.path.join(gold, "zigbee_ch15_4msps.cf32"), dtype=np.complex64)
+    path = tmp_path / "zb.sc16"
+    synth.quantize(x, 2).tofile(path)
+    scan = ZigbeeScan(channels=[15], source=FileSource(str(path), sample_format=2), timeout=None)
+    msgs = scan.run()
+    want = json.load(open(os.path.join(gold, "zigbee_ch15_expected.json")))
+    sent = [f["psdu"] for f in want["sent"]]
+    got = {m.mpdu.hex() for m in msgs}
+    assert len(sent) > 3 and sum(s in got for s in sent) >= len(sent) - 1

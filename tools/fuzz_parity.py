@@ -22,45 +22,55 @@ def main(budget_s):
         kind = rng.choice(list(n_cases))
         seed = int(rng.integers(1 << 30))
         first = int(rng.integers(0, 1 << 40))
+        fmt = int(rng.choice([0, 0, 1, 2]))       # cf32 / sc8 / sc16 input
+
+        def prep(x):
+            """-> (what the receiver gets, what the oracle gets)"""
+            if fmt == 0:
+                return x, x
+            q = synth.quantize(x, fmt, full_scale=float(rng.choice([0.0, 0.5, 4.0])))   # incl. clipping / coarse
+            return q, oracle.from_int(q)
         if kind == "btle":
             n = int(rng.integers(5, 1 << 19))
             ch = int(rng.integers(0, 40))
             x, _ = synth.btle_capture(n, channel=ch, seed=seed, mean_gap=float(rng.choice([300.0, 3000.0, 30000.0])))
-            with SnoutRx(proto=0, channel=ch) as rx:
-                got = rx.process(x, first_sample_index=first)
+            xin, x = prep(x)
+            with SnoutRx(proto=0, channel=ch, sample_format=fmt) as rx:
+                got = rx.process(xin, first_sample_index=first)
             want, _ = oracle.btle_segment(x, channel=ch, first_sample_index=first)
-            desc = f"btle n={n} ch={ch} seed={seed}"
+            desc = f"btle n={n} ch={ch} seed={seed} fmt={fmt}"
         elif kind == "zigbee":
             n = int(rng.integers(9, 1 << 19))
             core = int(rng.choice([1024, 2048, 4096, 8192, 16384]))
             warm = int(rng.choice([w for w in (256, 512, 1024, 2048) if w < core]))
             x, _ = synth.zigbee_capture(n, seed=seed, mean_gap=float(rng.choice([400.0, 4000.0, 20000.0])),
                                         cfo_max_hz=float(rng.choice([0.0, 40e3, 100e3])))
-            if rng.random() < 0.2:
+            if rng.random() < 0.2 and fmt == 0:
                 x[int(rng.integers(0, n))] = np.nan
-            with SnoutRx(proto=1, channel=11, zb_core=core, zb_warmup=warm) as rx:
-                got = rx.process(x, first_sample_index=first)
+            xin, x = prep(x)
+            with SnoutRx(proto=1, channel=11, zb_core=core, zb_warmup=warm, sample_format=fmt) as rx:
+                got = rx.process(xin, first_sample_index=first)
             want = oracle.zigbee_segment(x, channel=11, core=core, warmup=warm, first_sample_index=first)
-            desc = f"zigbee n={n} core={core} warm={warm} seed={seed}"
+            desc = f"zigbee n={n} core={core} warm={warm} seed={seed} fmt={fmt}"
         elif kind == "btle40":
             n = int(rng.integers(640, 40 * 60000))
             x, _ = synth.wideband_capture(0, n, seed=seed, bins=sorted(rng.choice(40, 6, replace=False).tolist()),
                                           mean_gap=float(rng.choice([2000.0, 8000.0])))
-            x = x[:n]
-            with SnoutRx(proto=0, n_channels=40) as rx:
-                got = rx.process(x, first_sample_index=first)
+            xin, x = prep(x[:n])
+            with SnoutRx(proto=0, n_channels=40, sample_format=fmt) as rx:
+                got = rx.process(xin, first_sample_index=first)
             want = oracle.wideband_segment(x, 0, first_sample_index=first)
-            desc = f"btle40 n={n} seed={seed}"
+            desc = f"btle40 n={n} seed={seed} fmt={fmt}"
         else:
             n = int(rng.integers(256, 16 * 60000))
             core = int(rng.choice([1024, 2048, 4096]))
             x, _ = synth.wideband_capture(1, n, seed=seed, bins=sorted(rng.choice(16, 4, replace=False).tolist()),
                                           mean_gap=float(rng.choice([3000.0, 12000.0])), max_len=40)
-            x = x[:n]
-            with SnoutRx(proto=1, n_channels=16, zb_core=core) as rx:
-                got = rx.process(x, first_sample_index=first)
+            xin, x = prep(x[:n])
+            with SnoutRx(proto=1, n_channels=16, zb_core=core, sample_format=fmt) as rx:
+                got = rx.process(xin, first_sample_index=first)
             want = oracle.wideband_segment(x, 1, first_sample_index=first, core=core)
-            desc = f"zigbee16 n={n} core={core} seed={seed}"
+            desc = f"zigbee16 n={n} core={core} seed={seed} fmt={fmt}"
         n_cases[kind] += 1
         if not same(got, want):
             print("MISMATCH:", desc, "first_index", first, len(got), len(want), flush=True)
