@@ -188,11 +188,17 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
                 bool any = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t n = n_base + 4u * lane + (uint32_t)j;
-                    hit[j] = (aa_window(prev[j], cur[j], lane) == aa) && n >= 124u && n < nb;
+                    hit[j] = aa_window(prev[j], cur[j], lane) == aa;
                     any |= hit[j];
                 }
-                if (__ballot(any) != 0ull) append_hits(hit, lane, n_base, list, cap, cnt);
+                if (__ballot(any) != 0ull) {        // rare: the range tests are only paid here
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t n = n_base + 4u * lane + (uint32_t)j;
+                        hit[j] = hit[j] && n >= 124u && n < nb;
+                    }
+                    append_hits(hit, lane, n_base, list, cap, cnt);
+                }
                 if (lane == it - it0) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) keep[j] = cur[j];

@@ -69,3 +69,14 @@ def test_other_workloads_keep_the_contract(workload, samples, cpu, name):
     c = d["config"]
     assert c["decoded_crc_ok_per_gpu"] >= c["expected_crc_ok_per_gpu"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["value"] > d["cpu_baseline"]["value"]
+
+
+def test_integer_input_format_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--format", "sc8", "--steps", "3",
+                        "--warmup", "1", "--samples", "6e7", "--cpu-samples", "2e7"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["dtype"] == "i8->i32" and "sc8" in d["config"]["workload"]
+    # 2 B per sample: the algorithmic bytes of the roofline follow the format
+    assert abs(d["roofline"]["algorithmic_bytes"] - (2 * 6e7 + 160 * d["config"]["packets_per_gpu"])) < 1
+    assert d["config"]["decoded_crc_ok_per_gpu"] >= d["config"]["expected_crc_ok_per_gpu"] > 0
