@@ -10,6 +10,7 @@ recorded/synthetic capture "elapsed" is capture time (sample_index / fs), not wa
 """
 from __future__ import annotations
 
+import os
 import socket
 import time
 from typing import Callable, Dict, Iterable, List, Optional
@@ -45,9 +46,12 @@ class FileSource(IqSource):
         self.sample_format = int(sample_format)
 
     def read(self, channel: int) -> np.ndarray:
+        # memory-mapped: a scan touches one segment at a time, captures can be larger than RAM
+        if os.path.getsize(self.path) == 0:
+            return np.zeros(0, dtype=np.complex64)
         if self.sample_format == 0:
-            return np.fromfile(self.path, dtype=np.complex64)
-        a = np.fromfile(self.path, dtype=np.int8 if self.sample_format == 1 else np.int16)
+            return np.memmap(self.path, dtype=np.complex64, mode="r")
+        a = np.memmap(self.path, dtype=np.int8 if self.sample_format == 1 else np.int16, mode="r")
         return a[:a.size // 2 * 2].reshape(-1, 2)
 
 

@@ -149,3 +149,18 @@ def test_sc16_file_through_zigbee_scan(tmp_path):
     sent = [f["psdu"] for f in want["sent"]]
     got = {m.mpdu.hex() for m in msgs}
     assert len(sent) > 3 and sum(s in got for s in sent) >= len(sent) - 1
+
+
+def test_sharded_wideband_scan_on_int8_input():
+    """Segments of an sc8 wideband capture through ShardedScan == the capture processed whole."""
+    import torch
+    from snout_amd.sharded import ShardedScan
+    x, truth = synth.wideband_capture(0, 40 * 120000, seed=61, bins=[2, 11, 31], mean_gap=5000.0)
+    q = torch.from_numpy(synth.quantize(x, 1)).cuda()
+    with _rx(proto=0, n_channels=40, sample_format=1) as rx:
+        whole = rx.process(q)
+    sc = ShardedScan(proto=0, n_channels=40, seg_len=40 * 30000, sample_format=1)
+    got = sc.run(len(x), lambda a, b: q[2 * a:2 * b])
+    sc.close()
+    key = lambda r: {(int(p["channel"]), int(p["sample_index"]), bytes(p["bytes"][:p["len"]])) for p in r if p["crc_ok"]}
+    assert key(got) == key(whole) and len(key(whole)) >= 0.9 * len(truth)
