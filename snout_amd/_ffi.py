@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsnout_rx.so")
+LIB_PATH = os.environ.get("SNOUT_RX_LIB") or os.path.join(_HERE, "lib", "libsnout_rx.so")   # override: A/B builds
 
 ABI_VERSION = 1
 PROTO_BTLE, PROTO_ZIGBEE = 0, 1
