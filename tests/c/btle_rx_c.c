@@ -1,10 +1,11 @@
 /*
  * A plain-C consumer of include/snout_rx.h: what a maintainer's cgo / JNI / N-API / C glue would do.
- * Reads a cf32 capture, runs the BTLE receive path through the C ABI only (no Python, no torch)
- * and prints the btle_rx-format lines, like the child process the reference spawns
- * (snout/util/btle.py:53,63-69).  Built by tests/test_c_abi_gpu.py with gcc + -lsnout_rx.
+ * Reads a capture (cf32, or the int8 IQ a HackRF writes and upstream btle_rx reads, or int16),
+ * runs the BTLE receive path through the C ABI only (no Python, no torch) and prints the
+ * btle_rx-format lines, like the child process the reference spawns (snout/util/btle.py:53,63-69).
+ * Built by tests/test_c_abi_gpu.py with gcc + -lsnout_rx.
  *
- *   btle_rx_c <capture.cf32> <channel> <t0_epoch>
+ *   btle_rx_c <capture> <channel> <t0_epoch> [cf32|sc8|sc16]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,14 +14,17 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 4) { fprintf(stderr, "usage: %s capture.cf32 channel t0\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s capture channel t0 [cf32|sc8|sc16]\n", argv[0]); return 2; }
+    uint32_t fmt = SNOUT_FMT_CF32, sample_bytes = 8;
+    if (argc > 4 && !strcmp(argv[4], "sc8")) { fmt = SNOUT_FMT_SC8; sample_bytes = 2; }
+    if (argc > 4 && !strcmp(argv[4], "sc16")) { fmt = SNOUT_FMT_SC16; sample_bytes = 4; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END);
     const long bytes = ftell(f);
     fseek(f, 0, SEEK_SET);
-    const uint64_t n = (uint64_t)bytes / 8u;
-    float* iq = (float*)malloc((size_t)bytes);
+    const uint64_t n = (uint64_t)bytes / sample_bytes;
+    void* iq = malloc((size_t)bytes);
     if (fread(iq, 1, (size_t)bytes, f) != (size_t)bytes) { fprintf(stderr, "short read\n"); return 2; }
     fclose(f);
 
@@ -31,6 +35,7 @@ int main(int argc, char** argv)
     cfg.n_channels = 1;
     cfg.channel = (uint32_t)atoi(argv[2]);
     cfg.device = -1;
+    cfg.reserved[1] = fmt;
     snout_rx* h = NULL;
     int rc = snout_rx_create(&cfg, &h);
     if (rc) { fprintf(stderr, "create: %s: %s\n", snout_strerror(rc), snout_last_error()); return 1; }

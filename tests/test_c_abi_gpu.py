@@ -36,3 +36,25 @@ def test_plain_c_program_decodes_the_golden_capture(tmp_path):
         m = BtleMessage.fromraw(ln)
         assert m and ln.endswith(b"CRC0\n") and f"Ch{t['channel']}".encode() in ln
         assert abs(m.timestamp - (t0 + t["sample_index"] / 4e6)) < 1e-3
+
+
+def test_plain_c_program_on_hackrf_int8_iq(tmp_path):
+    """The same C program fed interleaved int8 IQ (SNOUT_FMT_SC8), the format upstream btle_rx reads."""
+    from snout_amd import synth
+    exe = str(tmp_path / "btle_rx_c")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "btle_rx_c.c"), "-o", exe,
+                           "-L", LIBDIR, "-lsnout_rx", "-Wl,-rpath," + LIBDIR])
+    x = np.fromfile(os.path.join(ROOT, "tests", "golden", "btle_ch37_4msps.cf32"), dtype=np.complex64)
+    cap = tmp_path / "btle_ch37.sc8"
+    synth.quantize(x, 1).tofile(cap)
+    r = subprocess.run([exe, str(cap), "37", "1567108496.0", "sc8"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = r.stdout.splitlines(keepends=True)
+    truth = json.load(open(os.path.join(ROOT, "tests", "golden", "btle_ch37_truth.json")))
+    assert len(lines) == len(truth) == 8 and all(ln.endswith(b"CRC0\n") for ln in lines)
+    from snout_amd.message import BtleMessage
+    for ln, t in zip(lines, truth):
+        pdu = bytes.fromhex(t["pdu"])
+        m = BtleMessage.fromraw(ln)
+        assert m.sender == pdu[2:8][::-1].hex() and m.payload_hex == pdu[8:].hex()
