@@ -20,9 +20,14 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     const float base = z < 0.003921569f ? z : interp;
     const float PI = 3.14159265358979323846f, H = 1.57079632679489661923f;
     const bool xp = x >= 0.0f, yp = y >= 0.0f;
-    const float q_lt = xp ? (yp ? base : -base) : (yp ? PI - base : base - PI);
-    const float q_ge = yp ? (xp ? H - base : H + base) : (xp ? -H + base : -H - base);
-    const float ang = lt ? q_lt : q_ge;
+    // The oracle's eight branch values are +-m with m = base | PI - base (|y| < |x|) or
+    // H - base | H + base (otherwise): base - PI == -(PI - base), -H + base == -(H - base) and
+    // -H - base == -(H + base) exactly (rounding is symmetric), so one magnitude and the sign of
+    // "y >= 0" (a compare, not the sign bit: -0.0 counts as non-negative) give the same bits.
+    const float m_lt = xp ? base : PI - base;
+    const float m_ge = xp ? H - base : H + base;
+    const float m = lt ? m_lt : m_ge;
+    const float ang = __uint_as_float(__float_as_uint(m) ^ (yp ? 0u : 0x80000000u));
     return (ya > 0.0f || xa > 0.0f) ? ang : 0.0f;
 }
 
