@@ -101,6 +101,7 @@ struct snout_rx {
     BtleCtx btle, btle2, btle3;
     ZbCtx zb2;                // (second Zigbee work set; the first is `zb`)
     hipStream_t tail_stream = nullptr;
+    bool sync_call = false;   // inside snout_rx_process*: nothing to overlap, the tail stays on the caller's stream
     ZbCtx zb;
     PfbCtx pfb;
     DevBuf d_iq;              // staging for snout_rx_process (host input)
@@ -145,6 +146,11 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // (~8 us each): the narrowband BTLE path, whose kernel is the whole front end, reuses the pair
     // around the kernel as start-of-segment and front-end-done events.
     const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;
+    // A one-segment-at-a-time call has nothing to overlap the tail with: it stays on the caller's
+    // stream, in order behind the front end.  (A cross-stream wait on a front end that runs for
+    // several ms was seen to resolve 10.8 ms late in some processes: 802.15.4 at 1e9 samples then
+    // took 16 ms instead of 5.2 ms, with the same kernel durations.)
+    hipStream_t tail = h->sync_call ? st : h->tail_stream;
     if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_t0, st));
     // the tail that last used this work set must be done; usually it is, and a wait that is not
     // enqueued is one barrier packet less between two front-end kernels
@@ -181,20 +187,20 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
             if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s, ch_fmt)) return rc;
         }
         if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_front, st));
-        SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, nb_btle ? s.ev_k1 : s.ev_front, 0));
-        if (int rc = b.enqueue_tail(n_ch, s.first_index, h->tail_stream, s)) return rc;
-        SNOUT_HIP(hipEventRecord(s.ev_compute, h->tail_stream));
-        SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], h->tail_stream));
+        if (!h->sync_call) SNOUT_HIP(hipStreamWaitEvent(tail, nb_btle ? s.ev_k1 : s.ev_front, 0));
+        if (int rc = b.enqueue_tail(n_ch, s.first_index, tail, s)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
+        SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
         return 0;
     } else {
         ZbCtx& z = zb_of(h, s);
         if (int rc = z.reserve(n_ch)) return rc;
         if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
-        SNOUT_HIP(hipStreamWaitEvent(h->tail_stream, s.ev_front, 0));
-        if (int rc = z.enqueue_tail(n_ch, s.first_index, h->tail_stream, s, !h->wide)) return rc;
-        SNOUT_HIP(hipEventRecord(s.ev_compute, h->tail_stream));
-        SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], h->tail_stream));
+        if (!h->sync_call) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
+        if (int rc = z.enqueue_tail(n_ch, s.first_index, tail, s, !h->wide)) return rc;
+        SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
+        SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
         return 0;
     }
 }
@@ -202,18 +208,19 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
 // Totals (and `spec` records, speculatively) -> pinned host memory on the copy stream.
 static int enqueue_copy(snout_rx* h, ResultSlot& s, uint64_t spec)
 {
-    SNOUT_HIP(hipStreamWaitEvent(h->copy_stream, s.ev_compute, 0));
-    SNOUT_HIP(hipMemcpyAsync(s.h_totals, s.d_totals.p, 16, hipMemcpyDeviceToHost, h->copy_stream));
+    // one-segment-at-a-time calls stay on the caller's stream throughout (see enqueue_segment)
+    hipStream_t cs = h->sync_call ? s.stream : h->copy_stream;
+    if (!h->sync_call) SNOUT_HIP(hipStreamWaitEvent(cs, s.ev_compute, 0));
+    SNOUT_HIP(hipMemcpyAsync(s.h_totals, s.d_totals.p, 16, hipMemcpyDeviceToHost, cs));
     s.spec_copied = 0;
     if (spec) {
         const uint64_t room = s.d_out.cap / sizeof(snout_pkt);
         spec = spec < room ? spec : room;
         if (int rc = s.ensure_host(spec)) return rc;
-        SNOUT_HIP(hipMemcpyAsync(s.h_recs, s.d_out.p, spec * sizeof(snout_pkt), hipMemcpyDeviceToHost,
-                                 h->copy_stream));
+        SNOUT_HIP(hipMemcpyAsync(s.h_recs, s.d_out.p, spec * sizeof(snout_pkt), hipMemcpyDeviceToHost, cs));
         s.spec_copied = spec;
     }
-    SNOUT_HIP(hipEventRecord(s.ev_copy, h->copy_stream));
+    SNOUT_HIP(hipEventRecord(s.ev_copy, cs));
     return 0;
 }
 
@@ -527,6 +534,8 @@ int snout_rx_process_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
     // synchronous form: no speculation; records are DMA'd straight into `out` when it is pinned
     const uint64_t spec_save = h->spec;
     h->spec = 0;
+    struct SyncGuard { snout_rx* h; ~SyncGuard() { h->sync_call = false; } } guard{h};
+    h->sync_call = true;      // also covers a rerun after a capacity overflow (finish_slot)
     int rc = snout_rx_submit_dev(h, iq_dev, n_samples, first_sample_index, hip_stream);
     h->spec = spec_save;
     if (rc) return rc;

@@ -53,6 +53,8 @@ __device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t
 // zero-state response of the single-pole IIR to its samples (double, fixed order), from which
 // zb_iir_fold / zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the
 // oracle): four threads per sub-block sum 16 terms each in sequence, S = (P0 + P1) + (P2 + P3).
+constexpr uint32_t kDiscChunks = 4;     // 1024-sample chunks per zb_discrim block
+
 template <int FMT>
 __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, uint64_t n,
                                                   uint64_t iq_stride, uint64_t d_stride, uint64_t nsb,
@@ -62,46 +64,56 @@ __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, u
 {
     __shared__ float tab[257];
     __shared__ double wts[64];
-    __shared__ float ang_s[1024];
+    __shared__ float ang_s[2][1024];
     for (uint32_t i = threadIdx.x; i < 257; i += 256) tab[i] = atan_tab[i];
     if (threadIdx.x < 64) wts[threadIdx.x] = iir_w[threadIdx.x];
     __syncthreads();
     const uint32_t slot = blockIdx.y;
     const char* x = reinterpret_cast<const char*>(iq) + (uint64_t)fmt_bytes(FMT) * slot * iq_stride;
-    const uint64_t t0 = (uint64_t)blockIdx.x * 1024u + 4u * threadIdx.x;      // this thread's 4 samples
-    float ang[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (t0 < n) {
-        float2 xs[5];
-        xs[0] = t0 ? iq_sample<FMT>(x, t0 - 1u) : make_float2(0.0f, 0.0f);
-        if (t0 + 3u < n) {
-            iq_quad<FMT>(x, t0, &xs[1]);
-        } else {
+    // A block walks kDiscChunks consecutive 1024-sample chunks, so the table fill above (a fifth of
+    // the instructions of a one-chunk block) is paid once per 4096 samples.  The S_j sums of chunk c
+    // are taken by wave c mod 4 from a double-buffered copy of the chunk's values while the other
+    // waves go on to the next chunk.
+    for (uint32_t c = 0; c < kDiscChunks; c++) {
+        const uint64_t chunk = (uint64_t)blockIdx.x * kDiscChunks + c;
+        if (chunk * 1024u >= d_stride) break;
+        const uint64_t t0 = chunk * 1024u + 4u * threadIdx.x;      // this thread's 4 samples
+        float ang[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (t0 < n) {
+            float2 xs[5];
+            xs[0] = t0 ? iq_sample<FMT>(x, t0 - 1u) : make_float2(0.0f, 0.0f);
+            if (t0 + 3u < n) {
+                iq_quad<FMT>(x, t0, &xs[1]);
+            } else {
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) xs[1 + k] = t0 + k < n ? iq_sample<FMT>(x, t0 + k) : make_float2(0.0f, 0.0f);
+                for (uint32_t k = 0; k < 4u; k++) xs[1 + k] = t0 + k < n ? iq_sample<FMT>(x, t0 + k) : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const float2 a = xs[k + 1], p = xs[k];
+                const float re = a.x * p.x + a.y * p.y;          // contraction is off: products round first
+                const float im = a.y * p.x - a.x * p.y;
+                float v = fast_atan2f_tab(im, re, tab);
+                if (!(fabsf(v) <= 4.0f)) v = 0.0f;              // non-finite input: defined as 0 (as the oracle)
+                ang[k] = t0 + k < n ? v : 0.0f;
+            }
         }
+        *reinterpret_cast<float4*>(&d[(uint64_t)slot * d_stride + t0]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+        float* as = ang_s[c & 1u];
+        *reinterpret_cast<float4*>(&as[4u * threadIdx.x]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
+        __syncthreads();
+        if ((threadIdx.x >> 6) == (c & 3u)) {
+            const uint32_t l = threadIdx.x & 63u;
+            const uint32_t sb = l >> 2, part = l & 3u;          // 16 sub-blocks x 4 parts
+            double acc = 0.0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) {
-            const float2 a = xs[k + 1], p = xs[k];
-            const float re = a.x * p.x + a.y * p.y;          // contraction is off: products round first
-            const float im = a.y * p.x - a.x * p.y;
-            float v = fast_atan2f_tab(im, re, tab);
-            if (!(fabsf(v) <= 4.0f)) v = 0.0f;              // non-finite input: defined as 0 (as the oracle)
-            ang[k] = t0 + k < n ? v : 0.0f;
+            for (uint32_t k = 0; k < 16u; k++)
+                acc = acc + wts[63u - (16u * part + k)] * (double)as[64u * sb + 16u * part + k];
+            acc = acc + __shfl_down(acc, 1);                    // P0 + P1 (part 0), P2 + P3 (part 2)
+            acc = acc + __shfl_down(acc, 2);                    // (P0 + P1) + (P2 + P3)
+            const uint64_t j = chunk * 16u + sb;
+            if (part == 0u && j < nsb) S[(uint64_t)slot * nsb + j] = acc;
         }
-    }
-    if (t0 < d_stride) *reinterpret_cast<float4*>(&d[(uint64_t)slot * d_stride + t0]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
-    *reinterpret_cast<float4*>(&ang_s[4u * threadIdx.x]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
-    __syncthreads();
-    if (threadIdx.x < 64u) {
-        const uint32_t sb = threadIdx.x >> 2, part = threadIdx.x & 3u;      // 16 sub-blocks x 4 parts
-        double acc = 0.0;
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; k++)
-            acc = acc + wts[63u - (16u * part + k)] * (double)ang_s[64u * sb + 16u * part + k];
-        acc = acc + __shfl_down(acc, 1);                    // P0 + P1 (part 0), P2 + P3 (part 2)
-        acc = acc + __shfl_down(acc, 2);                    // (P0 + P1) + (P2 + P3)
-        const uint64_t j = (uint64_t)blockIdx.x * 16u + sb;
-        if (part == 0u && j < nsb) S[(uint64_t)slot * nsb + j] = acc;
     }
 }
 
@@ -1122,7 +1134,7 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
     if (n < 9u) return 0;   // no interpolator window fits: nothing to launch
     if (d_iq) {             // otherwise the fused channelizer has already written d and S
 #define SNOUT_ZBD(F)                                                                                  \
-    hipLaunchKernelGGL(zb_discrim<F>, dim3(cdiv(d_stride, 1024), n_slots), dim3(256), 0, st, d_iq, n, \
+    hipLaunchKernelGGL(zb_discrim<F>, dim3(cdiv(d_stride, 1024 * kDiscChunks), n_slots), dim3(256), 0, st, d_iq, n, \
                        iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(), \
                        d_S.as<double>())
         if (fmt == kFmtSc8) SNOUT_ZBD(kFmtSc8);
