@@ -224,8 +224,13 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         lds_barrier();
         if (tile + 1u < t_last) {
             const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
+            if (in1 + NEW <= n) {                 // uniform: all NEW samples exist, no per-lane range tests
 #pragma unroll
-            for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in1 + 2ull * (uint64_t)(t + k * NT));
+                for (int k = 0; k < NPRE; k++) pre[k] = iq_pair_raw<FMT>(x, in1 + 2ull * (uint64_t)(t + k * NT));
+            } else {
+#pragma unroll
+                for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in1 + 2ull * (uint64_t)(t + k * NT));
+            }
         }
 
         // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product
@@ -368,11 +373,13 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int sy = 0; sy < 15; sy++) {
                     const float2 b4 = col[(4 * sy + 4 + j) * ROW];
-                    const bool bit = ((a.x * b4.y) > (b4.x * a.y)) && (m0 + (uint64_t)(4 * sy + j) < nbits);
-                    bits |= (bit ? 1u : 0u) << sy;
+                    bits |= ((a.x * b4.y) > (b4.x * a.y) ? 1u : 0u) << sy;
                     a = b4;
                 }
-                pend = bits;
+                // symbols whose bit exists (m0 + 4 sy + j < nbits): a prefix of the 15, as one mask
+                const uint32_t left = nbits > m0 ? (uint32_t)(nbits - m0 < 64u ? nbits - m0 : 64u) : 0u;   // uniform
+                const uint32_t cnt = left > (uint32_t)j ? (left - (uint32_t)j + 3u) >> 2 : 0u;
+                pend = bits & ((1u << (cnt < 15u ? cnt : 15u)) - 1u);
                 carry = a;                                               // y_k[m0 + 60 + j]
                 have_prev = true;
                 if (tile + 1u == n_tiles)                                // no later tile: symbol 15 has no partner
