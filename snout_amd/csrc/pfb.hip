@@ -317,11 +317,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             const float2* col = &us[M2 * (k % M1) + (k / M1)];
             float2 p = seg ? col[(8 * seg - 1) * ROW] : prevy[k];
             float dv[8];
+            const uint32_t left = n_out > m0 ? (uint32_t)(n_out - m0 < (uint64_t)T ? n_out - m0 : (uint64_t)T) : 0u;   // outputs of this tile that exist (uniform)
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float2 a = col[(8 * seg + j) * ROW];
                 const float v = zb_discriminate(a, p, atan_s);
-                dv[j] = (m0 + (uint64_t)(8 * seg + j) < n_out) ? v : 0.0f;
+                dv[j] = ((uint32_t)(8 * seg + j) < left) ? v : 0.0f;
                 dl[k * DLROW + 8 * seg + j] = dv[j];
                 p = a;
             }
