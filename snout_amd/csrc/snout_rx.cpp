@@ -147,9 +147,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // around the kernel as start-of-segment and front-end-done events.
     const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;
     // A one-segment-at-a-time call has nothing to overlap the tail with: it stays on the caller's
-    // stream, in order behind the front end.  (A cross-stream wait on a front end that runs for
-    // several ms was seen to resolve 10.8 ms late in some processes: 802.15.4 at 1e9 samples then
-    // took 16 ms instead of 5.2 ms, with the same kernel durations.)
+    // stream, in order behind the front end (no event wait between the two, 2-4 % faster).
     hipStream_t tail = h->sync_call ? st : h->tail_stream;
     if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_t0, st));
     // the tail that last used this work set must be done; usually it is, and a wait that is not

@@ -1023,7 +1023,7 @@ int ZbCtx::reserve(uint64_t n)
     n_waves = cdiv(total_lanes, 64);
     nt = (core + warmup) / 64u + 1u;
     tiles_per_slot = cdiv(lanes_per_slot, kScanTile);
-    stream_words = n / 64u + 4u;                    // at most one chip per sample
+    stream_words = (n / 64u + 5u) & ~1ull;          // at most one chip per sample; even: cleared in 16-byte units
     if (n >= (1ull << 31)) {    // chip and lane-relative indices are 32-bit
         set_last_error("Zigbee segment of %llu channel samples: at most 2^31 - 1 per call", (unsigned long long)n);
         return SNOUT_ERANGE;
@@ -1050,6 +1050,16 @@ int ZbCtx::reserve(uint64_t n)
     return 0;
 }
 
+// Zero-fill of the chip streams.  A kernel of our own rather than hipMemsetAsync: for the 62 MB of a
+// 1e9-sample segment the runtime's memset was seen to hold the host until the stream had drained
+// and then some (kernels of the tail launched 11 ms after zb_mm had finished, in some processes:
+// 16 ms per segment instead of 5).
+__global__ __launch_bounds__(256) void zb_clear(ulonglong2* __restrict__ p, uint64_t n16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += stride) p[i] = make_ulonglong2(0ull, 0ull);
+}
+
 // a7 and the glue before it: stitched chip streams -> sinks -> per-lane records (after zb_mm).
 int ZbCtx::launch_sinks(uint64_t first_index, hipStream_t st)
 {
@@ -1058,7 +1068,11 @@ int ZbCtx::launch_sinks(uint64_t first_index, hipStream_t st)
     uint32_t* offs = owned + total_lanes;
     uint32_t* tsum = offs + total_lanes;
     uint32_t* slot_total = tsum + (uint64_t)tiles_per_slot * n_slots;
-    SNOUT_HIP(hipMemsetAsync(d_stream.p, 0, stream_words * n_slots * 8u, st));
+    {
+        const uint64_t n16 = stream_words * n_slots / 2u;             // stream_words is even
+        hipLaunchKernelGGL(zb_clear, dim3((uint32_t)std::min<uint64_t>(cdiv(n16, 256), 4096u)), dim3(256), 0, st,
+                           d_stream.as<ulonglong2>(), n16);
+    }
     hipLaunchKernelGGL(zb_stitch, dim3(tiles_per_slot, n_slots), dim3(256), 0, st,
                        d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(), lanes_per_slot, core, warmup,
                        tiles_per_slot, first_owned, owned, tsum);
