@@ -36,13 +36,19 @@ extern "C" {
 #define SNOUT_PROTO_BTLE   0u
 #define SNOUT_PROTO_ZIGBEE 1u
 
-/* input sample formats (snout_rx_cfg.reserved[1]).  Integer samples stand for the cf32 samples
+/* input sample formats (snout_rx_cfg.sample_format).  Integer samples stand for the cf32 samples
  * v * 2^-7 (sc8) / v * 2^-15 (sc16): conversion and scale are exact in fp32, so results are bit-
  * identical to processing the converted capture as cf32. */
 #define SNOUT_FMT_CF32 0u   /* interleaved float32 I,Q (numpy.complex64, gr_complex), 8 B/sample       */
 #define SNOUT_FMT_SC8  1u   /* interleaved int8 I,Q: HackRF transfers, the input of upstream btle_rx
                                (SURVEY Appendix A.1), 2 B/sample                                     */
 #define SNOUT_FMT_SC16 2u   /* interleaved int16 I,Q (USRP sc16 captures), 4 B/sample                */
+
+/* snout_rx_cfg.flags */
+#define SNOUT_CFG_KEEP_CHANNEL_IQ 1u  /* a wideband handle keeps channel IQ in HBM (unfused kernels;
+                                         needed for the SNOUT_STAGE_CHAN_IQ tap).  Default: the
+                                         channelizer feeds the BTLE bit planes / the 802.15.4
+                                         discriminator rows directly                              */
 
 /* error codes */
 #define SNOUT_OK          0
@@ -78,10 +84,9 @@ typedef struct snout_rx_cfg {
                                  multiples of 64, warm-up < core; the timing loop needs >= 256      */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
-    uint32_t reserved[4];     /* [0] bit 0: a wideband handle keeps channel IQ in HBM (unfused kernels;
-                                 needed for the SNOUT_STAGE_CHAN_IQ tap).  Default: the channelizer
-                                 feeds the BTLE bit planes / the 802.15.4 discriminator rows directly
-                                 [1] SNOUT_FMT_* of every iq pointer handed to this handle (0 = cf32) */
+    uint32_t flags;           /* SNOUT_CFG_* bits                                                */
+    uint32_t sample_format;   /* SNOUT_FMT_* of every iq pointer handed to this handle (0 = cf32)  */
+    uint32_t reserved[2];     /* zero                                                            */
 } snout_rx_cfg;
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
@@ -118,7 +123,7 @@ int  snout_rx_create (const snout_rx_cfg* cfg, snout_rx** out);
 void snout_rx_destroy(snout_rx* h);
 
 /* One capture segment, synchronous. iq = interleaved (re,im) in the handle's sample format (cf32
- * unless cfg.reserved[1] says otherwise), 16-byte aligned, n_samples complex samples.
+ * unless cfg.sample_format says otherwise), 16-byte aligned, n_samples complex samples.
  * Packets are written in ascending (channel, sample_index) order. *n_out receives the number of
  * packets found (may exceed cap -> SNOUT_EOVERFLOW, first cap records valid).
  *

@@ -39,7 +39,8 @@ class RxCfg(C.Structure):
                 ("taps_per_branch", C.c_uint32), ("channel", C.c_uint32),
                 ("access_addr", C.c_uint32), ("crc_init", C.c_uint32),
                 ("chip_threshold", C.c_uint32), ("zb_core", C.c_uint32), ("zb_warmup", C.c_uint32),
-                ("max_hits", C.c_uint32), ("device", C.c_int32), ("reserved", C.c_uint32 * 4)]
+                ("max_hits", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("sample_format", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class RxProf(C.Structure):

@@ -140,7 +140,7 @@ static ZbCtx& zb_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->z
 static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
 {
     const void* ch_iq = s.iq;
-    int ch_fmt = (int)h->cfg.reserved[1];          // the channelizer always emits cf32
+    int ch_fmt = (int)h->cfg.sample_format;          // the channelizer always emits cf32
     uint64_t n_ch = s.n_in, ch_stride = s.n_in;
     // Every event on the caller's stream is a barrier packet between consecutive front-end kernels
     // (~8 us each): the narrowband BTLE path, whose kernel is the whole front end, reuses the pair
@@ -156,8 +156,8 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         SNOUT_HIP(hipStreamWaitEvent(st, h->ws_free[s.work_set], 0));
     // fused wideband modes (unless the caller keeps channel IQ for the CHAN_IQ tap): BTLE hard bits
     // straight into the bit planes, 802.15.4 discriminator output straight into the Zigbee context
-    const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.reserved[0] & 1u);
-    const bool fused_zb = h->wide && h->cfg.proto == SNOUT_PROTO_ZIGBEE && !(h->cfg.reserved[0] & 1u);
+    const bool fused = h->wide && h->cfg.proto == SNOUT_PROTO_BTLE && !(h->cfg.flags & SNOUT_CFG_KEEP_CHANNEL_IQ);
+    const bool fused_zb = h->wide && h->cfg.proto == SNOUT_PROTO_ZIGBEE && !(h->cfg.flags & SNOUT_CFG_KEEP_CHANNEL_IQ);
     if (h->wide) {
         n_ch = h->pfb.n_out_for(s.n_in);
         BtleCtx& bw = btle_of(h, s);
@@ -308,7 +308,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     if (c.zb_warmup == 0) c.zb_warmup = 512;
     if (c.n_channels == 0) c.n_channels = 1;
     int rc = SNOUT_EINVAL;
-    if (c.reserved[1] > SNOUT_FMT_SC16) { set_last_error("sample format %u", c.reserved[1]); goto fail; }
+    if (c.sample_format > SNOUT_FMT_SC16) { set_last_error("sample format %u", c.sample_format); goto fail; }
     if (c.proto == SNOUT_PROTO_ZIGBEE &&
         (c.zb_core < 1024 || c.zb_core > (1u << 24) || c.zb_warmup > (1u << 20))) {
         set_last_error("zb_core %u / zb_warmup %u out of range", c.zb_core, c.zb_warmup);
@@ -443,7 +443,7 @@ int snout_rx_submit_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
         if (h->wide) {
             h->pfb.n_out = 0;
             if (n_samples) {
-                if (int rc = h->pfb.run(iq_dev, n_samples, s.stream, nullptr, 0, nullptr, (int)h->cfg.reserved[1])) return rc;
+                if (int rc = h->pfb.run(iq_dev, n_samples, s.stream, nullptr, 0, nullptr, (int)h->cfg.sample_format)) return rc;
             }
         }
         s.h_totals[0] = s.h_totals[1] = s.h_totals[2] = 0;
@@ -566,7 +566,7 @@ int snout_rx_process(snout_rx* h, const void* iq_host, uint64_t n_samples,
     *n_out = 0;
     SNOUT_HIP(hipSetDevice(h->device));
     if (n_samples) {
-        const uint64_t bytes = n_samples * sample_bytes(h->cfg.reserved[1]);
+        const uint64_t bytes = n_samples * sample_bytes(h->cfg.sample_format);
         if (int rc = h->d_iq.ensure(bytes)) return rc;
         SNOUT_HIP(hipMemcpy(h->d_iq.p, iq_host, bytes, hipMemcpyHostToDevice));
     }
@@ -599,7 +599,7 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;     // see enqueue_segment
     SNOUT_HIP(hipEventElapsedTime(&out->ms_total, nb_btle ? h->hist_k0[s.hist_idx] : s.ev_t0, s.ev_copy));
     SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->hist_k0[s.hist_idx], h->hist_k1[s.hist_idx]));
-    out->bytes_algorithmic = (uint64_t)sample_bytes(h->cfg.reserved[1]) * h->last_n + 160ull * h->last_pkts;
+    out->bytes_algorithmic = (uint64_t)sample_bytes(h->cfg.sample_format) * h->last_n + 160ull * h->last_pkts;
     out->n_hits = s.h_totals[0];
     out->dominant_launches = 1;
     if (h->wide) {

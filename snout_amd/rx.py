@@ -41,8 +41,8 @@ class SnoutRx:
                          access_addr=access_addr, crc_init=crc_init,
                          chip_threshold=chip_threshold, zb_core=zb_core, zb_warmup=zb_warmup,
                          max_hits=max_hits, device=device)
-        cfg.reserved[0] = 1 if keep_channel_iq else 0      # unfused wideband BTLE (CHAN_IQ tap)
-        cfg.reserved[1] = int(sample_format)               # FMT_CF32 / FMT_SC8 / FMT_SC16
+        cfg.flags = 1 if keep_channel_iq else 0            # SNOUT_CFG_KEEP_CHANNEL_IQ: unfused wideband kernels (CHAN_IQ tap)
+        cfg.sample_format = int(sample_format)             # FMT_CF32 / FMT_SC8 / FMT_SC16
         self.sample_format = int(sample_format)
         self._h = C.c_void_p()
         _ffi.check(self._lib.snout_rx_create(C.byref(cfg), C.byref(self._h)))

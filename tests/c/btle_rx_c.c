@@ -35,7 +35,7 @@ int main(int argc, char** argv)
     cfg.n_channels = 1;
     cfg.channel = (uint32_t)atoi(argv[2]);
     cfg.device = -1;
-    cfg.reserved[1] = fmt;
+    cfg.sample_format = fmt;
     snout_rx* h = NULL;
     int rc = snout_rx_create(&cfg, &h);
     if (rc) { fprintf(stderr, "create: %s: %s\n", snout_strerror(rc), snout_last_error()); return 1; }

@@ -77,3 +77,32 @@ def test_bad_arguments_are_rejected():
     rec = np.zeros(1, dtype=_ffi.PKT_DTYPE)
     buf = C.create_string_buffer(16)
     assert lib.snout_btle_format_line(rec.ctypes.data_as(C.c_void_p), 4e6, 0.0, 0, 0, buf, 16) == -1
+
+
+def test_cfg_layout_matches_the_header():
+    """snout_rx_cfg as ctypes sees it == the C struct: compiled probe of offsetof / sizeof."""
+    import ctypes as C
+    import os
+    import subprocess
+    import tempfile
+    from snout_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "snout_rx.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu\n", sizeof(snout_rx_cfg), offsetof(snout_rx_cfg, device),
+           offsetof(snout_rx_cfg, flags), offsetof(snout_rx_cfg, sample_format),
+           offsetof(snout_rx_cfg, reserved), sizeof(snout_pkt));
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        exe = os.path.join(d, "p")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), os.path.join(d, "p.c"), "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    want = [C.sizeof(_ffi.RxCfg), _ffi.RxCfg.device.offset, _ffi.RxCfg.flags.offset,
+            _ffi.RxCfg.sample_format.offset, _ffi.RxCfg.reserved.offset, _ffi.PKT_DTYPE.itemsize]
+    assert got == want == [64, 44, 48, 52, 56, 160]
