@@ -64,7 +64,7 @@ struct ResultSlot {
     uint32_t* h_totals = nullptr;        // pinned, 16 u32
     snout_pkt* h_recs = nullptr;         // pinned staging for records
     uint64_t h_cap = 0;
-    hipEvent_t ev_t0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_front = nullptr,
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_front = nullptr,
                ev_compute = nullptr, ev_copy = nullptr;
     // bookkeeping of the submitted segment
     const void* iq = nullptr;           // cf32 / sc8 / sc16 as the handle is configured (iq_fmt.h)

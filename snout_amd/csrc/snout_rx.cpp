@@ -54,7 +54,6 @@ int ResultSlot::init()
     if (int rc = d_totals.ensure(kTotalsBytes)) return rc;
     SNOUT_HIP(hipHostMalloc((void**)&h_totals, 64, hipHostMallocDefault));
     memset(h_totals, 0, 64);
-    SNOUT_HIP(hipEventCreate(&ev_t0));
     SNOUT_HIP(hipEventCreate(&ev_k0));
     SNOUT_HIP(hipEventCreate(&ev_k1));
     SNOUT_HIP(hipEventCreate(&ev_front));
@@ -70,10 +69,10 @@ void ResultSlot::destroy()
     if (h_totals) (void)hipHostFree(h_totals);
     if (h_recs) (void)hipHostFree(h_recs);
     h_totals = nullptr; h_recs = nullptr; h_cap = 0;
-    if (ev_t0) {
-        (void)hipEventDestroy(ev_t0); (void)hipEventDestroy(ev_k0); (void)hipEventDestroy(ev_k1);
+    if (ev_k0) {
+        (void)hipEventDestroy(ev_k0); (void)hipEventDestroy(ev_k1);
         (void)hipEventDestroy(ev_front); (void)hipEventDestroy(ev_compute); (void)hipEventDestroy(ev_copy);
-        ev_t0 = nullptr;
+        ev_k0 = nullptr;
     }
 }
 
@@ -149,7 +148,8 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // A one-segment-at-a-time call has nothing to overlap the tail with: it stays on the caller's
     // stream, in order behind the front end (no event wait between the two, 2-4 % faster).
     hipStream_t tail = h->sync_call ? st : h->tail_stream;
-    if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_t0, st));
+    // (the first kernel's start event ev_k0 also marks the start of the segment: every event on the
+    //  caller's stream is a barrier packet, so there is no separate one)
     // the tail that last used this work set must be done; usually it is, and a wait that is not
     // enqueued is one barrier packet less between two front-end kernels
     if (hipEventQuery(h->ws_free[s.work_set]) != hipSuccess)
@@ -596,8 +596,7 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     memset(out, 0, sizeof(*out));
     if (!h->last || !h->last->timed) { set_last_error("no processed segment to profile"); return SNOUT_EINVAL; }
     ResultSlot& s = *h->last;
-    const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;     // see enqueue_segment
-    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, nb_btle ? h->hist_k0[s.hist_idx] : s.ev_t0, s.ev_copy));
+    SNOUT_HIP(hipEventElapsedTime(&out->ms_total, h->hist_k0[s.hist_idx], s.ev_copy));
     SNOUT_HIP(hipEventElapsedTime(&out->ms_dominant, h->hist_k0[s.hist_idx], h->hist_k1[s.hist_idx]));
     out->bytes_algorithmic = (uint64_t)sample_bytes(h->cfg.sample_format) * h->last_n + 160ull * h->last_pkts;
     out->n_hits = s.h_totals[0];
