@@ -147,7 +147,12 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     const bool nb_btle = !h->wide && h->cfg.proto == SNOUT_PROTO_BTLE;
     // A one-segment-at-a-time call has nothing to overlap the tail with: it stays on the caller's
     // stream, in order behind the front end (no event wait between the two, 2-4 % faster).
-    hipStream_t tail = h->sync_call ? st : h->tail_stream;
+    // So does the (tiny) BTLE tail of a small pipelined segment: the two cross-stream hand-overs cost
+    // more than the ~50 us of kernels they would overlap (48 wideband segments of 2^24 samples: 12.3
+    // -> 9.9 ms); behind a 1e9-sample front end the separate stream is worth 5 %.
+    const uint64_t ch_samples = (h->wide ? h->pfb.n_out_for(s.n_in) * h->cfg.n_channels : s.n_in);
+    const bool inline_tail = h->sync_call || (h->cfg.proto == SNOUT_PROTO_BTLE && ch_samples < (1ull << 26));
+    hipStream_t tail = inline_tail ? st : h->tail_stream;
     // (the first kernel's start event ev_k0 also marks the start of the segment: every event on the
     //  caller's stream is a barrier packet, so there is no separate one)
     // the tail that last used this work set must be done; usually it is, and a wait that is not
@@ -185,7 +190,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
             if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s, ch_fmt)) return rc;
         }
         if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_front, st));
-        if (!h->sync_call) SNOUT_HIP(hipStreamWaitEvent(tail, nb_btle ? s.ev_k1 : s.ev_front, 0));
+        if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, nb_btle ? s.ev_k1 : s.ev_front, 0));
         if (int rc = b.enqueue_tail(n_ch, s.first_index, tail, s)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
@@ -195,7 +200,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         if (int rc = z.reserve(n_ch)) return rc;
         if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
-        if (!h->sync_call) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
+        if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
         if (int rc = z.enqueue_tail(n_ch, s.first_index, tail, s, !h->wide)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
