@@ -45,16 +45,27 @@ def dedup_records(rec: np.ndarray, tol: int = 0) -> np.ndarray:
     preamble symbols, 64 samples apart, and its timing loop locks at its own phase)."""
     if rec.size == 0:
         return rec
-    order = np.lexsort((rec["sample_index"], rec["channel"], rec["proto"]))
-    rec = rec[order]
-    same_ch = (rec["proto"][1:] == rec["proto"][:-1]) & (rec["channel"][1:] == rec["channel"][:-1])
-    dsi = rec["sample_index"][1:].astype(np.int64) - rec["sample_index"][:-1].astype(np.int64)
-    dup = same_ch & (dsi <= tol)
-    if tol > 0:
-        dup &= (rec["len"][1:] == rec["len"][:-1]) & np.all(rec["bytes"][1:] == rec["bytes"][:-1], axis=1)
+    si = rec["sample_index"]
+    if int(si.max()) < (1 << 48):
+        # one stable sort of a packed 64-bit key instead of a three-key lexsort
+        key = (rec["proto"].astype(np.uint64) << np.uint64(60)) | (rec["channel"].astype(np.uint64) << np.uint64(48)) | si
+        order = np.argsort(key, kind="stable")
+        key = key[order]
+        dup = ((key[1:] >> np.uint64(48)) == (key[:-1] >> np.uint64(48))) & (key[1:] - key[:-1] <= np.uint64(tol))
+    else:
+        order = np.lexsort((si, rec["channel"], rec["proto"]))
+        p, c, x = rec["proto"][order], rec["channel"][order], si[order]
+        dup = (p[1:] == p[:-1]) & (c[1:] == c[:-1]) & (x[1:] - x[:-1] <= np.uint64(tol))
     keep = np.ones(rec.size, dtype=bool)
-    keep[1:] = ~dup
-    return rec[keep]
+    if tol > 0:
+        # only candidate pairs pay for the comparison of their bytes
+        idx = np.nonzero(dup)[0]
+        a, b = rec[order[idx + 1]], rec[order[idx]]
+        same = (a["len"] == b["len"]) & np.all(a["bytes"] == b["bytes"], axis=1)
+        keep[idx[same] + 1] = False
+    else:
+        keep[1:] = ~dup
+    return rec[order[keep]]
 
 
 def gather_records(rec: np.ndarray, device=None, group=None) -> Optional[np.ndarray]:

@@ -105,3 +105,41 @@ def test_dedup_with_tolerance():
     assert [int(x["sample_index"]) for x in d] == [1000, 5000, 1001]
     r["bytes"][1, 1] = 9                                       # different payload: not a duplicate
     assert len(sdist.dedup_records(r, tol=64)) == 4
+
+
+def test_dedup_records_matches_the_three_key_definition():
+    """dedup_records (packed-key sort) == sort by (proto, channel, sample_index) + adjacent-duplicate
+    rule, with and without the 802.15.4 tolerance, also when sample_index does not fit the packed key."""
+    from snout_amd._ffi import PKT_DTYPE
+    from snout_amd.dist import dedup_records
+    rng = np.random.default_rng(3)
+
+    def reference(rec, tol):
+        order = np.lexsort((rec["sample_index"], rec["channel"], rec["proto"]))
+        r = rec[order]
+        keep = [0]
+        for i in range(1, r.size):
+            j = i - 1                       # the record just before it in sorted order
+            dup = (r["proto"][i] == r["proto"][j] and r["channel"][i] == r["channel"][j]
+                   and int(r["sample_index"][i]) - int(r["sample_index"][j]) <= tol)
+            if dup and tol > 0:
+                dup = r["len"][i] == r["len"][j] and bytes(r["bytes"][i]) == bytes(r["bytes"][j])
+            if not dup:
+                keep.append(i)
+        return r[keep]
+
+    for base in (0, (1 << 52)):
+        n = 3000
+        rec = np.zeros(n, dtype=PKT_DTYPE)
+        rec["proto"] = rng.integers(0, 2, n)
+        rec["channel"] = rng.integers(0, 40, n)
+        rec["sample_index"] = base + rng.integers(0, 200000, n).astype(np.uint64)
+        rec["len"] = rng.integers(5, 40, n)
+        rec["bytes"][:, :8] = rng.integers(0, 256, (n, 8))
+        dup = rec[:600].copy()
+        dup["sample_index"][300:] += rng.integers(1, 700, 300).astype(np.uint64)      # near-duplicates
+        allrec = np.concatenate([rec, dup])
+        rng.shuffle(allrec)
+        for tol in (0, 520):
+            assert np.array_equal(dedup_records(allrec.copy(), tol=tol), reference(allrec, tol)), (base, tol)
+    assert dedup_records(np.zeros(0, dtype=PKT_DTYPE)).size == 0
