@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X IQ->packets receive path.
+"""bench.py — benchmark of the MI355X IQ->packets receive path on BASELINE.json's metric.
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d cfg #2): single-channel BTLE GFSK demod +
-access-address correlate + de-whiten/CRC decode on 1e9 synthetic cf32 IQ samples per GPU, input
-already resident in HBM when the timed region starts.  A "step" is one pass of the whole path
-over that batch, packet records landed in host memory.
+    python bench.py --gpus 1 --steps K --warmup W
+        headline: cfg #3 (BASELINE.json configs[2]): 80 Msps wideband capture -> 40-channel polyphase
+        channelizer -> BTLE demod + access-address correlate + de-whiten/CRC on every channel, 8e8
+        cf32 samples (10 s of band) resident in HBM.  `roofline` is the channelizer kernel
+        (HBM fraction of the 8 TB/s spec peak, of the read rate measured in this process, and the
+        fp32 FLOP fraction); `cpu_baseline` times the CPU oracle on a bounded sample with 1 thread
+        and with all host cores.  `other_workloads` carries cfg #2 (single-channel BTLE, 1e9
+        samples), cfg #4 (16-channel 802.15.4, 3.2e8), single-channel 802.15.4 (1e9) and cfg #5 on
+        this one GPU, measured in the same process under the same contract.
 
-    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        cfg #5 (configs[4]): the BTLE 40-channel and the 802.15.4 16-channel wideband scans run
+        concurrently; each capture is cut into segments of 2^24 input samples that overlap by the
+        longest packet, segment i -> rank i mod N, every rank pumps its segments through its GPU,
+        the decoded records are gathered to rank 0 over RCCL and de-duplicated there, all inside the
+        timed region.  Weak scaling: every rank holds 10 s of both bands (its share of an N x 10 s
+        capture), so per-GPU work is fixed.
 
-Multi-GPU: capture segments shard across ranks with no data-path collective (weak scaling: every
-rank processes its own 1e9-sample segment); decoded packet records are gathered to rank 0 with
-RCCL inside the timed region.
+`--workload X` runs one workload alone (N = 1: that workload is the headline; N > 1: every rank
+processes its own copy of it, records gathered per step).
 
-`--workload` selects one of the other SURVEY §8d configurations (cfg3: 40-channel BTLE wideband,
-cfg4: 16-channel 802.15.4 wideband, zigbee1: single-channel 802.15.4) with the same contract; the
-default, and the line the round is judged on, is cfg2.
-
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the stream the
-dominant kernel runs on; `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded
-sample of the same workload on this host's cores.
+A "step" is one pass of the whole receive path over the resident capture, packet records landed in
+host memory (rank 0's for N > 1).  Prints ONE JSON line (rank 0).  Kernel durations are HIP-event
+pairs recorded on the kernel's own stream during the timed steps.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -34,180 +40,185 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "complex-IQ Msamples/s through channelize+demod; decoded pkts/s; HBM GB/s %peak"   # BASELINE.json
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-TILE = 1 << 22                  # samples in the host-generated, noise-free packet tile
+FP32_PEAK_TFLOPS = 157.3        # MI355X fp32 vector peak (same guide)
 SIGMA = 0.05
+SEG = 1 << 24                   # cfg #5 segment length in input samples
 
+# flop per input sample of the channelizer: (M P 4 + 5 M log2 M) / D
+PFB_FLOP = {40: (40 * 16 * 4 + 5 * 40 * np.log2(40)) / 20, 16: (16 * 16 * 4 + 5 * 16 * 4) / 8}
 
 WORKLOADS = {
-    # name: (proto, n_channels, channel, default samples per GPU, record bytes gathered, metric, description)
-    "cfg2": (0, 1, 37, 1e9, 80, "complex-IQ Msamples/s through BTLE demod+correlate+decode",
+    # name: (proto, n_channels, channel, samples per GPU, gathered record bytes, description)
+    "cfg2": (0, 1, 37, 1e9, 80,
              "cfg2: single-channel BTLE (ch37) GFSK demod + access-address correlate + dewhiten/CRC"),
-    "cfg3": (0, 40, 0, 40 * (1 << 22), 80,
-             "wideband complex-IQ Msamples/s through 40-channel PFB + BTLE demod+correlate+decode",
+    "cfg3": (0, 40, 0, 8e8, 80,
              "cfg3: 80 Msps wideband -> 40-channel polyphase channelizer -> BTLE receive on every channel"),
-    "cfg4": (1, 16, 0, 16 * (1 << 23), 160,
-             "wideband complex-IQ Msamples/s through 16-channel PFB + 802.15.4 receive",
+    "cfg4": (1, 16, 0, 3.2e8, 160,
              "cfg4: 32 Msps wideband -> 16-channel polyphase channelizer -> 802.15.4 receive on every channel"),
-    "zigbee1": (1, 1, 11, 1e9, 160, "complex-IQ Msamples/s through 802.15.4 O-QPSK receive",
+    "zigbee1": (1, 1, 11, 1e9, 160,
                 "single-channel 802.15.4 (ch11): discriminator + DC removal + M&M clock recovery + packet sink"),
 }
+CFG5_DESCR = ("cfg5: BTLE 40-channel (80 Msps) and 802.15.4 16-channel (32 Msps) wideband scans concurrently, "
+              "10 s of each band per GPU in 2^24-sample overlapping segments, segment i -> rank i mod N")
 
-
-def make_tile(workload: str, seed: int):
-    """Noise-free host tile of the workload's traffic and its truth list."""
-    from snout_amd import synth
-    if workload == "cfg2":
-        return synth.btle_capture(TILE, channel=37, seed=seed, noise=False)
-    if workload == "zigbee1":
-        return synth.zigbee_capture(TILE, channel=11, seed=seed, noise=False)
-    if workload == "cfg3":
-        return synth.wideband_capture(0, 40 * (1 << 16), seed=seed, sigma=0.0)
-    if workload == "cfg4":
-        return synth.wideband_capture(1, 16 * (1 << 17), seed=seed, sigma=0.0)
-    raise SystemExit(f"unknown workload {workload}")
-
-
-def make_workload(n_samples: int, seed: int, device, workload: str = "cfg2"):
-    """Synthetic capture in HBM: a seeded tile of packets (exponential gaps, random CFO/phase/
-    length) repeated to n_samples, plus independent AWGN on every sample generated on
-    the device. Returns (float32 tensor [2n], expected CRC-ok count, set of expected PDUs)."""
-    import torch
-    tile, truth = make_tile(workload, seed)
-    TILE = tile.size
-    t = torch.from_numpy(tile.view(np.float32)).to(device)
-    x = torch.empty(2 * n_samples, dtype=torch.float32, device=device)
-    g = torch.Generator(device=device)
-    g.manual_seed(1000 + seed)
-    reps = (n_samples + TILE - 1) // TILE
-    for r in range(reps):
-        lo = r * 2 * TILE
-        hi = min(lo + 2 * TILE, 2 * n_samples)
-        seg = x[lo:hi]
-        torch.randn(seg.shape, generator=g, device=device, out=seg)
-        seg.mul_(SIGMA).add_(t[:hi - lo])
-    full = n_samples // TILE
-    rem = n_samples - full * TILE
-    if workload == "cfg2":
-        expect = full * len(truth) + sum(1 for p in truth if p.sample_index + 1600 < rem)
-    else:
-        # truth indices of the wideband tiles are at the channel rate and 802.15.4 frames are up to
-        # 4256 samples long: count whole tiles only, and allow the frames a repetition cuts short
-        # (cfg4: the synthetic 2 MHz raster makes adjacent 802.15.4 channels overlap spectrally,
-        # DESIGN.md §6.7 -- with all 16 bins busy about half of the frames survive, on the oracle too)
-        expect = int((0.4 if workload == "cfg4" else 0.9) * full * len(truth))
-    pdus = {p.payload for p in truth}
-    torch.cuda.synchronize(device)
-    return x, expect, pdus
-
-
-# bounded CPU sample per workload: ~10-30 s of single-thread oracle time for the three passes
+# bounded CPU samples: about 10 s of single-thread oracle time per leg
 CPU_SAMPLES = {"cfg2": 2.5e8, "cfg3": 40 * (1 << 21), "cfg4": 16 * (1 << 21), "zigbee1": 1 << 26}
 CPU_SOURCE = {"cfg2": "oracle/oracle_btle.c", "cfg3": "oracle/oracle_pfb.c + oracle_btle.c",
               "cfg4": "oracle/oracle_pfb.c + oracle_zigbee.c", "zigbee1": "oracle/oracle_zigbee.c"}
 
 
-def cpu_baseline(x_dev, n_sample: int, passes: int, workload: str = "cfg2"):
-    """Time the CPU oracle (single thread) on the first n_sample samples of the workload."""
+# ------------------------------------------------------------------------------------------------
+# synthetic captures
+# ------------------------------------------------------------------------------------------------
+def make_tile(workload: str, seed: int, n_tile: int = 0):
+    """Noise-free host tile of the workload's traffic and its truth list."""
+    from snout_amd import synth
+    if workload == "cfg2":
+        return synth.btle_capture(n_tile or (1 << 22), channel=37, seed=seed, noise=False)
+    if workload == "zigbee1":
+        return synth.zigbee_capture(n_tile or (1 << 22), channel=11, seed=seed, noise=False)
+    if workload == "cfg3":
+        return synth.wideband_capture(0, n_tile or 40 * (1 << 16), seed=seed, sigma=0.0)
+    if workload == "cfg4":
+        return synth.wideband_capture(1, n_tile or 16 * (1 << 17), seed=seed, sigma=0.0)
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def resident_capture(tile: np.ndarray, n_samples: int, seed: int, device, shift: int = 0):
+    """Capture in HBM: the tile repeated to n_samples (starting `shift` samples before a tile
+    boundary) plus independent AWGN on every sample, generated on the device."""
+    import torch
+    L = tile.size
+    t = torch.from_numpy(np.ascontiguousarray(tile).view(np.float32)).to(device)
+    if shift:
+        t = torch.roll(t, 2 * (shift % L))
+    x = torch.empty(2 * n_samples, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + seed)
+    for lo in range(0, 2 * n_samples, 2 * L):
+        hi = min(lo + 2 * L, 2 * n_samples)
+        seg = x[lo:hi]
+        torch.randn(seg.shape, generator=g, device=device, out=seg)
+        seg.mul_(SIGMA).add_(t[:hi - lo])
+    torch.cuda.synchronize(device)
+    return x
+
+
+def expected_ok(workload: str, truth, tile_len: int, n_samples: int) -> int:
+    full = n_samples // tile_len
+    if workload == "cfg2":
+        rem = n_samples - full * tile_len
+        return full * len(truth) + sum(1 for p in truth if p.sample_index + 1600 < rem)
+    # wideband truth indices are at the channel rate and 802.15.4 frames are up to 4256 samples
+    # long: count whole tiles only, and allow for the frames a repetition cuts short (cfg4: the
+    # synthetic 2 MHz raster makes adjacent 802.15.4 channels overlap spectrally, DESIGN.md §6.7)
+    return int((0.4 if workload == "cfg4" else 0.9) * full * len(truth))
+
+
+def quantise(x, fmt: int):
+    """What an SDR's ADC path would have delivered: full scale = 1.25 x the largest component."""
+    import torch
+    bits = 7 if fmt == 1 else 15
+    scale = float(1 << bits) / (1.25 * float(x.abs().max()))
+    xi = torch.empty(x.shape, dtype=torch.int8 if fmt == 1 else torch.int16, device=x.device)
+    step = 1 << 26
+    for lo in range(0, x.numel(), step):
+        xi[lo:lo + step] = (x[lo:lo + step] * scale).round_().clamp_(-(1 << bits), (1 << bits) - 1)
+    return xi
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle: test infrastructure, here only as the thing timed beside the GPU)
+# ------------------------------------------------------------------------------------------------
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_leg(host: np.ndarray, workload: str, threads: int, passes: int):
     from oracle import oracle_py
-    oracle_py.lib()
-    host = x_dev[:2 * n_sample].cpu().numpy()
-    if host.dtype != np.float32:
-        host = oracle_py.from_int(host)     # the oracle's definition of integer input (untimed)
-    best = None
-    n_pk = 0
+    oracle_py.set_threads(threads)
+    best, n_pk = None, 0
     for _ in range(passes):
         t0 = time.perf_counter()
         if workload == "cfg2":
-            pk, _ = oracle_py.btle_segment(host, channel=37, cap=max(1024, n_sample // 2048))
+            pk = (oracle_py.narrowband_parallel(host, 0, 37) if threads > 1
+                  else oracle_py.btle_segment(host, channel=37, cap=max(1024, host.size // 4096))[0])
         elif workload == "zigbee1":
-            pk = oracle_py.zigbee_segment(host, channel=11)
+            pk = (oracle_py.narrowband_parallel(host, 1, 11) if threads > 1
+                  else oracle_py.zigbee_segment(host, channel=11))
+        elif threads > 1:
+            M = 40 if workload == "cfg3" else 16            # ~4 segments per thread, each a whole serial chain
+            seg = max(M * 8192, (host.size // 2 // (4 * threads)) // M * M)
+            pk = oracle_py.wideband_parallel(host, 0 if workload == "cfg3" else 1, seg)
         else:
             pk = oracle_py.wideband_segment(host, proto=0 if workload == "cfg3" else 1)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         n_pk = len(pk)
-    return n_sample / best / 1e6, n_pk, host
+    oracle_py.set_threads(1)
+    return best, n_pk
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
-    ap.add_argument("--samples", type=float, default=0,
-                    help="complex input samples per GPU per step (default: the workload's size)")
-    ap.add_argument("--format", choices=["cf32", "sc8", "sc16"], default="cf32",
-                    help="input sample format resident in HBM (cf32 is BASELINE's; sc8 = HackRF / upstream "
-                         "btle_rx int8 IQ, sc16 = USRP): the same capture quantised on the device")
-    ap.add_argument("--cpu-samples", type=float, default=0,
-                    help="samples of the CPU baseline leg (default: ~10-30 s of oracle time)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--sync", action="store_true",
-                    help="one segment at a time (no submit/collect pipelining); for profiling")
-    args = ap.parse_args()
+def cpu_baseline(x_dev, workload: str, n_sample: int):
+    """Two legs on the first n_sample samples of the resident capture: the scalar port on one
+    thread, and the same oracle with OpenMP over output times / channels / segments on all cores."""
+    from oracle import oracle_py
+    oracle_py.lib()
+    host = x_dev[:2 * n_sample].cpu().numpy()
+    if host.dtype != np.float32:
+        host = oracle_py.from_int(host)     # the oracle's definition of integer input (untimed)
+    ncores = oracle_py.hw_threads()
+    t1, n_pk = cpu_leg(host, workload, 1, passes=2)
+    tall, n_pk_all = cpu_leg(host, workload, ncores, passes=3)
+    assert abs(n_pk - n_pk_all) <= max(4, n_pk // 50), (n_pk, n_pk_all)     # segment seams may move a few records
+    return {"value": n_sample / t1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "first %.3g samples of the %s capture, %s, gcc -O3 -march=x86-64-v3, best of 2 passes"
+                      % (n_sample, workload, CPU_SOURCE[workload]),
+            "all_cores": {"value": n_sample / tall / 1e6, "unit": "Msamples/s", "cores": ncores,
+                          "how": "same oracle, one OpenMP task per overlapping segment (~4 per thread), each the "
+                                 "whole serial chain over every channel; best of 3 passes"},
+            "nproc": os.cpu_count(), "cpu_model": cpu_model(), "packets_in_sample": int(n_pk)}
 
+
+# ------------------------------------------------------------------------------------------------
+# one workload on one handle, pipelined submit / collect
+# ------------------------------------------------------------------------------------------------
+def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, world: int, fmt: int = 0,
+                 sync: bool = False, gather=None, keep_capture: bool = False):
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # one rank per GPU; SNOUT_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box
-    # with fewer GPUs than ranks (ranks then share devices; a debugging aid, not a measurement)
-    backend = os.environ.get("SNOUT_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
     from snout_amd.rx import SnoutRx
-    from snout_amd import dist as sdist
-
-    proto, n_ch, channel, n_default, rec_width, metric, descr = WORKLOADS[args.workload]
-    n = int(args.samples or n_default)
-    x, expect, pdus = make_workload(n, seed=2 + rank, device=device, workload=args.workload)
-    fmt = {"cf32": 0, "sc8": 1, "sc16": 2}[args.format]
+    proto, n_ch, channel, _, _, descr = WORKLOADS[name]
+    tile, truth = make_tile(name, seed=2 + rank)
+    x = resident_capture(tile, n, seed=2 + rank, device=device)
+    expect = expected_ok(name, truth, tile.size, n)
+    pdus = {p.payload for p in truth}
     if fmt:
-        # what the SDR's ADC path would have delivered: full scale = 1.25 x the largest component
-        bits = 7 if fmt == 1 else 15
-        scale = float(1 << bits) / (1.25 * float(x.abs().max()))
-        xi = torch.empty(x.shape, dtype=torch.int8 if fmt == 1 else torch.int16, device=device)
-        step = 1 << 26
-        for lo in range(0, x.numel(), step):
-            xi[lo:lo + step] = (x[lo:lo + step] * scale).round_().clamp_(-(1 << bits), (1 << bits) - 1)
-        x = xi
-        del xi
+        x = quantise(x, fmt)
         torch.cuda.empty_cache()
-    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=local_rank, sample_format=fmt)
-
-    # Pipelined steps: up to three segments are in flight, so the next front-end kernel is already
-    # queued when the previous one ends and the record D2H (copy stream) overlaps compute.  Every step's records are
-    # in host memory (and gathered to rank 0) before the timed region ends.
-    gather = sdist.AsyncRecordGather(device, width=rec_width) if world > 1 else None
+    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt)
 
     def finish_one():
         pk = rx.collect(copy=False)
         if gather is not None:
             # RCCL gather of this step's records to rank 0, overlapped with the next step
             if len(gather.inflight) == 2:
-                gather.finish(views=True)       # records are in rank 0's host memory; no host-side copy
+                gather.finish(views=True)
             gather.start(pk, rx.last_records_device()[0])      # packed from the device copy: no upload
         return pk
 
     def run_steps(k):
         last = None
-        if args.sync:
-            for i in range(k):
+        if sync:
+            for _ in range(k):
                 rx.submit(x, first_sample_index=rank * n)
                 last = finish_one()
             return last
@@ -221,12 +232,6 @@ def main():
             last = finish_one()
         return last
 
-    # prime the pipeline: first-use allocations of the three result slots and the HIP runtime's own
-    # lazily grown pools (two ~7 ms stalls were measured around the 11th and 16th submit of a process)
-    run_steps(24)
-    if args.warmup:
-        run_steps(args.warmup)
-
     def fence():
         torch.cuda.synchronize(device)
         if world > 1:
@@ -237,78 +242,314 @@ def main():
         while gather is not None and gather.inflight:
             gather.finish(views=True)
 
+    # prime the pipeline: first-use allocations of the result slots and the HIP runtime's own
+    # lazily grown pools (two ~7 ms stalls were measured around the 11th and 16th submit of a process)
+    run_steps(24 if n <= int(1.1e9) else 8)
+    if warmup:
+        run_steps(warmup)
     drain()
     fence()
     t0 = time.perf_counter()
-    pk = run_steps(args.steps)
+    run_steps(steps)
     drain()                 # every step's records are on rank 0 before the clock stops
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
-    # dominant-kernel durations of the timed steps: HIP events recorded on the kernel's stream during
-    # the timed region, read back only now (the library keeps the last 64 pairs)
-    k_ms = rx.profile_history()[-min(args.steps, 64):]
+    k_ms = rx.profile_history()[-min(steps, 64):]
 
     # correctness of the timed work: every generated packet decoded with a good CRC
     local = rx.process(x, first_sample_index=rank * n)
     n_ok = int(local["crc_ok"].sum())
     fcs = 3 if proto == 0 else 0        # BTLE records carry PDU + CRC24, truth holds the PDU; 802.15.4: PSDU incl. FCS
     seen = {bytes(p["bytes"][:p["len"] - fcs]) for p in local[:4096] if p["crc_ok"]}
-    assert n_ok >= expect, f"rank {rank}: decoded {n_ok} CRC-ok packets, expected >= {expect}"
+    assert n_ok >= expect, f"{name} rank {rank}: decoded {n_ok} CRC-ok packets, expected >= {expect}"
     assert seen <= pdus, "decoded a PDU that was never transmitted"
     prof = rx.profile()
+    k_avg = float(np.mean(k_ms))
+    if proto == 1 and n_ch == 1 and not sync:
+        # the 802.15.4 chain is several kernels on two streams: pipelined, its event pair also spans
+        # the overlap with the neighbouring steps, so its duration comes from one-at-a-time passes
+        ks = []
+        for _ in range(3):
+            rx.process(x, first_sample_index=rank * n, copy=False)
+            ks.append(rx.profile().ms_dominant)
+        k_avg = float(np.mean(ks))
+    algo = float(x.element_size() * 2) * n + 160.0 * len(local)
+    res = {"workload": "%s, %.3g %s samples per GPU resident in HBM" % (descr, n, ["cf32", "sc8", "sc16"][fmt]),
+           "value": n * world * steps / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3,
+           "steps": steps, "samples_per_gpu": n, "packets_per_gpu": int(len(local)),
+           "decoded_pkts_per_s": len(local) * world * steps / dt,
+           "decoded_crc_ok_per_gpu": n_ok, "expected_crc_ok_per_gpu": expect,
+           "kernel": prof.dominant_name, "kernel_ms": k_avg, "algorithmic_bytes": algo,
+           "achieved_GBps": algo / (k_avg * 1e-3) / 1e9, "frac": algo / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if n_ch > 1:
+        fl = PFB_FLOP[n_ch] * n
+        res["fp32"] = {"flop_per_sample": float(PFB_FLOP[n_ch]), "achieved_TFLOPs": fl / (k_avg * 1e-3) / 1e12,
+                       "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": fl / (k_avg * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+    rx.close()
+    if keep_capture:
+        return res, x
+    del x
+    torch.cuda.empty_cache()
+    return res, None
 
+
+def read_peak(x, device):
+    """Read-only streaming rate of the resident capture, measured in this process (GB/s)."""
+    import torch
+    from snout_amd import _ffi
+    lib = _ffi.load()
+    best, mean = C.c_float(0), C.c_float(0)
+    nbytes = min(x.numel() * x.element_size(), 8 << 30)
+    st = torch.cuda.current_stream(device).cuda_stream
+    _ffi.check(lib.snout_hbm_read_gbps(C.c_void_p(x.data_ptr()), nbytes, 10, C.c_void_p(st),
+                                       C.byref(best), C.byref(mean)))
+    return float(best.value), float(mean.value)
+
+
+def traffic_from_profiles(workload: str, kernel: str, n: int):
+    """PMC-derived HBM bytes per launch of the same kernel / workload, from the committed profile
+    pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected); None when there is none."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        tj = json.load(open(path))
+        for e in (tj if isinstance(tj, list) else [tj]):
+            if e.get("workload") == workload and e.get("workload_samples") == n and e.get("kernel") == kernel:
+                return e["traffic_bytes_per_launch"], "profiles/" + name
+            if "workload" not in e and workload == "cfg2" and e.get("workload_samples") == n and e.get("kernel") == kernel:
+                return e["traffic_bytes_per_launch"], "profiles/" + name
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# cfg #5: both wideband scans concurrently, sharded in 2^24-sample segments
+# ------------------------------------------------------------------------------------------------
+def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: float = 10.0, group=None):
+    import torch
+    import torch.distributed as dist
+    from snout_amd import dist as sdist
+    from snout_amd.sharded import ShardedScan, pump
+    nb_rank, nz_rank = int(80e6 * seconds), int(32e6 * seconds)
+    sb = ShardedScan(0, n_channels=40, seg_len=SEG, device=device.index)
+    sz = ShardedScan(1, n_channels=16, seg_len=SEG, device=device.index, handles=2)
+    # The virtual capture is N x `seconds` long and tile-periodic with a period that divides the
+    # segment length, so every segment starts on a tile boundary: the overlap a rank reads behind its
+    # segment i shows the same packets as the start of segment i+1 on the next rank (only the noise
+    # differs), and the duplicates meet in rank 0's de-duplication.  Each rank keeps ITS segments
+    # back to back in HBM: local segment j is global segment rank + j N.
+    tb, truth_b = make_tile("cfg3", seed=3, n_tile=sb.seg_len // 6)
+    tz, truth_z = make_tile("cfg4", seed=4, n_tile=sz.seg_len // 8)
+    assert sb.seg_len % tb.size == 0 and sz.seg_len % tz.size == 0
+    caps = []
+    for sc, tile, n_rank, seed in ((sb, tb, nb_rank, 3), (sz, tz, nz_rank, 4)):
+        n_total = n_rank * world
+        segs = sdist.shard_segments(n_total, sc.seg_len, sc.overlap, rank, world, sc.preroll)
+        n_local = len(segs) * sc.seg_len + sc.overlap + sc.preroll
+        x = resident_capture(tile, n_local, seed=seed + 10 * rank, device=device, shift=sc.preroll)
+        S, pre = sc.seg_len, sc.preroll
+
+        def source(a, b, x=x, S=S, pre=pre):
+            i = (a + pre) // S                      # global segment index (a = max(0, i S - preroll))
+            lo = (i // world) * S + (a - i * S) + pre
+            return x[2 * lo:2 * (lo + (b - a))]
+        caps.append((n_total, source, x))
+    (nb, srcb, xb), (nz, srcz, xz) = caps
+    on_gpu = world == 1 or dist.get_backend(group) == "nccl"
+    gdev = device if on_gpu else None
+    gb = sdist.AsyncRecordGather(gdev, group, width=80, dedup_tol=0)
+    gz = sdist.AsyncRecordGather(gdev, group, width=160, dedup_tol=8 * 64 + 8)
+    results = []
+
+    def one_step():
+        gb.begin(n_hint=nb_rank // 8000)
+        gz.begin(n_hint=nz_rank // 8000)
+        sb.start(nb, srcb, group, sink=gb)
+        sz.start(nz, srcz, group, sink=gz)
+        pump([sb, sz])
+        gb.launch()
+        gz.launch()
+        if len(gb.inflight) == 2:                   # the exchange of step i overlaps the kernels of step i+1
+            take()
+
+    def take():
+        b, z = gb.finish(views=True), gz.finish(views=True)      # zero-copy views of rank 0's pinned buffers
+        results.append((b[0], z[0]) if rank == 0 else None)
+        del results[:-1]
+
+    def drain():
+        while gb.inflight:
+            take()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier(group)
+        torch.cuda.synchronize(device)
+
+    for _ in range(max(2, warmup)):
+        one_step()
+    drain()
+    results.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    drain()                                         # every step's records are on rank 0, de-duplicated
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+        dt = float(tmax.item())
+    res = None
     if rank == 0:
-        total_samples = n * world * args.steps
-        k_avg_ms = float(np.mean(k_ms))
-        algo_bytes = float(x.element_size() * 2) * n + 160.0 * len(local)
-        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tpath):       # PMC-derived HBM bytes per launch of the same workload
-            tj = json.load(open(tpath))
-            if (args.workload == "cfg2" and fmt == 0 and tj.get("workload_samples") == n
-                    and tj.get("kernel") == prof.dominant_name):
-                traffic = tj["traffic_bytes_per_launch"]
-        out = {
-            "metric": metric,
-            "value": total_samples / dt / 1e6,
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if fmt == 0 else ("i8->i32" if (fmt == 1 and args.workload == "cfg2") else
-                                             args.format + "->f32"),
-            "data": "synthetic",
-            "config": {"workload": "%s, %.3g %s samples per GPU resident in HBM" % (descr, n, args.format),
-                       "samples_per_gpu": n, "packets_per_gpu": int(len(local)),
-                       "decoded_pkts_per_s": len(local) * world * args.steps / dt,
-                       "sharding": "segments per rank, RCCL gather of 160-B records" if world > 1
-                                   else "single segment",
-                       "decoded_crc_ok_per_gpu": n_ok, "expected_crc_ok_per_gpu": expect,
-                       "stepping": "one segment at a time" if args.sync else
-                                   "pipelined: record D2H of step i overlaps step i+1"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
-                                           "gfx950-corrected)" if traffic else None,
-                         "kernel": prof.dominant_name, "kernel_ms": k_avg_ms,
-                         "algorithmic_bytes": algo_bytes},
-        }
-        if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
-            ns = int(min(args.cpu_samples or CPU_SAMPLES[args.workload], n))
-            v, n_pk, _ = cpu_baseline(x, ns, passes=3, workload=args.workload)
-            out["cpu_baseline"] = {"value": v, "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                   "sample": "first %.3g samples of the same workload, best of 3 "
-                                             "passes, %s single thread" % (ns, CPU_SOURCE[args.workload])}
+        rb, rz = results[-1]
+        ok_b, ok_z = int(rb["crc_ok"].sum()), int(rz["crc_ok"].sum())
+        exp_b = int(0.9 * (nb // tb.size) * len(truth_b))
+        exp_z = int(0.4 * (nz // tz.size) * len(truth_z))
+        assert ok_b >= exp_b and ok_z >= exp_z, (ok_b, exp_b, ok_z, exp_z)
+        key = (rb["channel"].astype(np.uint64) << np.uint64(48)) | rb["sample_index"]
+        assert np.all(key[1:] > key[:-1]), "BTLE records on rank 0 are not sorted / de-duplicated"
+        fcs_ok = {bytes(p["bytes"][:p["len"] - 3]) for p in rb[:2048] if p["crc_ok"]}
+        assert fcs_ok <= {p.payload for p in truth_b}, "decoded a PDU that was never transmitted"
+        total = (nb + nz) * steps
+        res = {"workload": CFG5_DESCR, "value": total / dt / 1e6, "unit": "Msamples/s",
+               "ms_per_step": dt / steps * 1e3, "steps": steps,
+               "samples_per_gpu": nb_rank + nz_rank, "btle_samples_per_gpu": nb_rank, "zigbee_samples_per_gpu": nz_rank,
+               "segments_per_gpu": len(sb._segs) + len(sz._segs), "segment_samples": SEG,
+               "records_on_rank0": int(len(rb) + len(rz)), "decoded_crc_ok": ok_b + ok_z,
+               "expected_crc_ok": exp_b + exp_z, "decoded_pkts_per_s": (len(rb) + len(rz)) * steps / dt,
+               "sharding": "segment i -> rank i mod N; per step one all_gather of 80-B BTLE and one of 160-B "
+                           "802.15.4 records to rank 0 (%s), sort + de-duplication on rank 0's GPU, inside the "
+                           "timed region" % ("RCCL" if world > 1 and dist.get_backend(group) == "nccl" else
+                                             ("gloo" if world > 1 else "single rank: device copy")),
+               "algorithmic_bytes": 8.0 * (nb_rank + nz_rank) + 160.0 * (len(rb) + len(rz)) / world}
+        res["achieved_GBps"] = res["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9
+        res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
+    sb.close()
+    sz.close()
+    del xb, xz, caps
+    torch.cuda.empty_cache()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["cfg5"], default=None,
+                    help="run this workload alone (default: cfg3 + the others at N = 1, cfg5 at N > 1)")
+    ap.add_argument("--samples", type=float, default=0,
+                    help="complex input samples per GPU per step (default: the workload's BASELINE size)")
+    ap.add_argument("--seconds", type=float, default=10.0, help="cfg5: seconds of each band per GPU")
+    ap.add_argument("--format", choices=["cf32", "sc8", "sc16"], default="cf32",
+                    help="input sample format resident in HBM (cf32 is BASELINE's; sc8 = HackRF / upstream "
+                         "btle_rx int8 IQ, sc16 = USRP): the same capture quantised on the device")
+    ap.add_argument("--cpu-samples", type=float, default=0,
+                    help="samples of the CPU baseline legs (default: ~10 s of oracle time per leg)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="N = 1: skip the other_workloads block")
+    ap.add_argument("--sync", action="store_true",
+                    help="one segment at a time (no submit/collect pipelining); for profiling")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # one rank per GPU; SNOUT_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box
+    # with fewer GPUs than ranks (ranks then share devices; a debugging aid, not a measurement)
+    backend = os.environ.get("SNOUT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+    from snout_amd import dist as sdist
+    fmt = {"cf32": 0, "sc8": 1, "sc16": 2}[args.format]
+    headline = args.workload or ("cfg3" if world == 1 else "cfg5")
+    out = None
+
+    if headline == "cfg5":
+        r5 = run_cfg5(args.steps, args.warmup, device, rank, world, seconds=args.seconds)
+        if rank == 0:
+            out = {"metric": METRIC, "value": r5["value"], "unit": "Msamples/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": r5["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                   "data": "synthetic", "config": {k: r5[k] for k in r5 if k not in ("value", "unit", "ms_per_step", "steps")},
+                   "roofline": {"bound": "hbm", "achieved": r5["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": r5["frac"], "traffic": None, "kernel": "whole step (pfb_channelize<40>, "
+                                "pfb_channelize<16> and the 802.15.4 chain on small segments)",
+                                "kernel_ms": r5["ms_per_step"], "algorithmic_bytes": r5["algorithmic_bytes"],
+                                "note": "per-GPU algorithmic bytes over the whole step: small segments are "
+                                        "launch-bound, see the single-segment kernels' fractions at N = 1"}}
+    else:
+        n = int(args.samples or WORKLOADS[headline][3])
+        gather = sdist.AsyncRecordGather(device, width=WORKLOADS[headline][4]) if world > 1 else None
+        res, x = run_workload(headline, n, args.steps, args.warmup, device, rank, world, fmt=fmt, sync=args.sync,
+                              gather=gather, keep_capture=True)
+        if rank == 0:
+            traffic, tsrc = (traffic_from_profiles(headline, res["kernel"], n) if fmt == 0 else (None, None))
+            rbest, rmean = read_peak(x, device)
+            roof = {"bound": "hbm", "achieved": res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": res["frac"], "traffic": traffic, "traffic_source": tsrc,
+                    "kernel": res["kernel"], "kernel_ms": res["kernel_ms"], "algorithmic_bytes": res["algorithmic_bytes"],
+                    "measured_read_GBps": rbest, "measured_read_mean_GBps": rmean,
+                    "frac_of_measured_read": res["achieved_GBps"] / rbest if rbest else None}
+            if "fp32" in res:
+                roof["fp32"] = res["fp32"]
+            out = {"metric": METRIC, "value": res["value"], "unit": "Msamples/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "f32" if fmt == 0 else ("i8->i32" if (fmt == 1 and headline == "cfg2") else args.format + "->f32"),
+                   "data": "synthetic",
+                   "config": {"workload": res["workload"], "samples_per_gpu": n, "packets_per_gpu": res["packets_per_gpu"],
+                              "decoded_pkts_per_s": res["decoded_pkts_per_s"],
+                              "sharding": ("every rank its own segment, per-step RCCL gather of %d-B records"
+                                           % WORKLOADS[headline][4]) if world > 1 else "single segment",
+                              "decoded_crc_ok_per_gpu": res["decoded_crc_ok_per_gpu"],
+                              "expected_crc_ok_per_gpu": res["expected_crc_ok_per_gpu"],
+                              "stepping": "one segment at a time" if args.sync else
+                                          "pipelined: record D2H of step i overlaps step i+1"},
+                   "roofline": roof}
+            if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
+                ns = int(min(args.cpu_samples or CPU_SAMPLES[headline], n))
+                out["cpu_baseline"] = cpu_baseline(x, headline, ns)
+        del x
+        torch.cuda.empty_cache()
+        if world == 1 and args.workload is None and not args.no_others:
+            others = {}
+            k = max(3, min(args.steps, 10))
+            for name in ("cfg2", "cfg4", "zigbee1"):
+                r, _ = run_workload(name, int(WORKLOADS[name][3]), k, 1, device, 0, 1)
+                others[name] = {f: r[f] for f in ("workload", "value", "unit", "ms_per_step", "steps", "kernel",
+                                                  "kernel_ms", "frac", "achieved_GBps", "packets_per_gpu",
+                                                  "decoded_crc_ok_per_gpu", "expected_crc_ok_per_gpu")}
+                if "fp32" in r:
+                    others[name]["fp32_frac"] = r["fp32"]["frac"]
+            r5 = run_cfg5(max(3, min(args.steps, 5)), 1, device, 0, 1, seconds=args.seconds)
+            others["cfg5"] = {f: r5[f] for f in ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu",
+                                                 "records_on_rank0", "decoded_crc_ok", "expected_crc_ok", "frac",
+                                                 "achieved_GBps", "sharding")}
+            others["cfg5"]["note"] = "what `--gpus N` measures; this is its N = 1 point"
+            out["other_workloads"] = others
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

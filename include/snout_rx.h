@@ -166,6 +166,13 @@ int  snout_rx_profile(snout_rx* h, snout_rx_prof* out);
  * segments, oldest first.  Read after the fact so a pipelined run is not perturbed. */
 int  snout_rx_profile_history(snout_rx* h, float* ms, uint32_t cap, uint32_t* n_out);
 
+/* Measurement aid (bench.py, SURVEY.md §8d "measured-copy-peak"): read-only streaming rate, in GB/s,
+ * of `bytes` bytes of device memory at `dev` (a fully coalesced 16-byte-per-lane grid-stride read
+ * kernel, `reps` timed launches after one warm-up, HIP events on `hip_stream`).  Not part of the
+ * receive path; no reference counterpart. */
+int  snout_hbm_read_gbps(const void* dev, uint64_t bytes, uint32_t reps, void* hip_stream,
+                         float* gbps_best, float* gbps_mean);
+
 /* Host-side formatters for the two consumer contracts. */
 /* btle_rx stdout grammar (snout/core/message.py:214-215,226-236). Returns bytes written
  * (excluding NUL) or negative error. */

@@ -50,6 +50,17 @@ int      oracle_wideband_segment(const float* iq, uint64_t n, uint64_t first_ind
                                  uint32_t core, uint32_t warmup, snout_pkt* out, uint64_t cap,
                                  uint64_t* n_out);
 
+/* ---- threads (bench.py's cpu_baseline legs) ---- */
+int      oracle_set_threads(int n);      /* OpenMP threads for oracle_pfb / the parallel receivers; returns the setting */
+int      oracle_hw_threads(void);
+int      oracle_narrowband_parallel(const float* iq, uint64_t n, uint32_t proto, uint32_t channel,
+                                    uint32_t access_addr, uint32_t crc_init, uint32_t threshold, uint32_t core,
+                                    uint32_t warmup, uint64_t seg, uint64_t overlap, snout_pkt* out, uint64_t cap,
+                                    uint64_t* n_out);
+int      oracle_wideband_parallel(const float* iq, uint64_t n, uint32_t proto, uint32_t access_addr,
+                                  uint32_t crc_init, uint32_t threshold, uint32_t core, uint32_t warmup,
+                                  uint64_t seg, snout_pkt* out, uint64_t cap, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

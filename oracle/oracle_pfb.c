@@ -187,22 +187,158 @@ int oracle_wideband_segment(const float* iq, uint64_t n, uint64_t first_index, u
     float* y = (float*)malloc((size_t)M * nc * 2u * sizeof(float));
     if (!y) return -3;
     int rc = oracle_pfb(iq, n, M, y, nc);
+    /* the channels are independent: one OpenMP task per bin, each into its own buffer, joined in
+     * bin order (the all-cores leg of bench.py's cpu_baseline; with one thread this is the plain
+     * loop over the bins) */
+    (void)oracle_fast_atan2f(0.0f, 1.0f);       /* lazily built tables: before the threads start */
+    snout_pkt* part[40] = {0};
+    uint64_t got[40] = {0}, pcap[40];
+    int prc[40] = {0};
+    for (uint32_t b = 0; b < M; b++) {
+        pcap[b] = nc / 256u + 64u;
+        part[b] = (snout_pkt*)malloc((size_t)pcap[b] * sizeof(snout_pkt));
+        if (!part[b]) rc = -3;
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < (int)M; b++) {
+        if (rc) continue;
+        const float* yc = y + 2ull * (uint64_t)b * nc;
+        for (;;) {
+            if (proto == 0)
+                prc[b] = oracle_btle_segment(yc, nc, first_index, oracle_btle_bin_channel((uint32_t)b), access_addr,
+                                             crc_init, part[b], pcap[b], &got[b], NULL, 0, NULL);
+            else
+                prc[b] = oracle_zigbee_segment(yc, nc, first_index, oracle_zigbee_bin_channel((uint32_t)b), threshold,
+                                               core, warmup, part[b], pcap[b], &got[b]);
+            if (prc[b] != -5 || got[b] <= pcap[b]) break;
+            pcap[b] = got[b] + 64u;                       /* capacity: grow and redo this bin */
+            snout_pkt* np = (snout_pkt*)realloc(part[b], (size_t)pcap[b] * sizeof(snout_pkt));
+            if (!np) { prc[b] = -3; break; }
+            part[b] = np;
+        }
+    }
     uint64_t total = 0;
-    for (uint32_t b = 0; b < M && rc == 0; b++) {
-        uint64_t got = 0;
-        const float* yc = y + 2ull * b * nc;
-        snout_pkt* dst = total < cap ? out + total : out;
-        const uint64_t room = total < cap ? cap - total : 0;
-        if (proto == 0)
-            rc = oracle_btle_segment(yc, nc, first_index, oracle_btle_bin_channel(b), access_addr,
-                                     crc_init, dst, room, &got, NULL, 0, NULL);
-        else
-            rc = oracle_zigbee_segment(yc, nc, first_index, oracle_zigbee_bin_channel(b), threshold,
-                                       core, warmup, dst, room, &got);
-        if (rc == -5) rc = 0;
-        total += got;
+    for (uint32_t b = 0; b < M; b++) {
+        if (!rc && prc[b] && prc[b] != -5) rc = prc[b];
+        if (!rc && part[b]) {
+            for (uint64_t i = 0; i < got[b] && i < pcap[b]; i++)
+                if (total + i < cap) out[total + i] = part[b][i];
+            total += got[b];
+        }
+        free(part[b]);
     }
     free(y);
+    *n_out = total;
+    return rc ? rc : (total > cap ? -5 : 0);
+}
+
+/* ---- threads ---------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+int  oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+int  oracle_hw_threads(void) { return omp_get_num_procs(); }
+#else
+int  oracle_set_threads(int n) { (void)n; return 1; }
+int  oracle_hw_threads(void) { return 1; }
+#endif
+
+/* Overlapping segments of one narrowband capture in parallel (one OpenMP task per segment), the
+ * all-cores form of the single-channel receivers: segment s covers [s seg, (s+1) seg + overlap) and
+ * reports the packets that start before (s+1) seg.  out is NOT sorted across segments beyond the
+ * segment order; returns the total count in *n_out (-5 if it exceeds cap). */
+int oracle_narrowband_parallel(const float* iq, uint64_t n, uint32_t proto, uint32_t channel,
+                               uint32_t access_addr, uint32_t crc_init, uint32_t threshold, uint32_t core,
+                               uint32_t warmup, uint64_t seg, uint64_t overlap, snout_pkt* out, uint64_t cap,
+                               uint64_t* n_out)
+{
+    *n_out = 0;
+    if (seg == 0) return -1;
+    const uint64_t ns = (n + seg - 1) / seg;
+    (void)oracle_fast_atan2f(0.0f, 1.0f);       /* lazily built tables: before the threads start */
+    uint64_t* cnt = (uint64_t*)calloc(ns ? ns : 1, sizeof(uint64_t));
+    snout_pkt** part = (snout_pkt**)calloc(ns ? ns : 1, sizeof(snout_pkt*));
+    if (!cnt || !part) { free(cnt); free(part); return -3; }
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t s = 0; s < (int64_t)ns; s++) {
+        const uint64_t a = (uint64_t)s * seg;
+        const uint64_t b = a + seg + overlap < n ? a + seg + overlap : n;
+        const uint64_t pc = (b - a) / 256u + 64u;
+        snout_pkt* buf = (snout_pkt*)malloc((size_t)pc * sizeof(snout_pkt));
+        uint64_t got = 0;
+        int r = -3;
+        if (buf)
+            r = proto == 0 ? oracle_btle_segment(iq + 2 * a, b - a, a, channel, access_addr, crc_init, buf, pc, &got, NULL, 0, NULL)
+                           : oracle_zigbee_segment(iq + 2 * a, b - a, a, channel, threshold, core, warmup, buf, pc, &got);
+        if (r && r != -5) {
+#pragma omp critical
+            rc = r;
+        }
+        uint64_t keep = 0;
+        for (uint64_t i = 0; buf && i < got && i < pc; i++)
+            if (buf[i].sample_index < a + seg || (uint64_t)s + 1 == ns) buf[keep++] = buf[i];
+        part[s] = buf;
+        cnt[s] = keep;
+    }
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < ns; s++) {
+        for (uint64_t i = 0; i < cnt[s]; i++)
+            if (total + i < cap) out[total + i] = part[s][i];
+        total += cnt[s];
+        free(part[s]);
+    }
+    free(cnt);
+    free(part);
+    *n_out = total;
+    return rc ? rc : (total > cap ? -5 : 0);
+}
+
+/* Overlapping segments of one WIDEBAND capture in parallel: one OpenMP task per segment, each the
+ * whole single-threaded chain (channelizer + every channel's receiver; the inner parallel loops run
+ * serially inside a task).  seg must be a multiple of M (keeps the channelizer's phase).  The
+ * all-cores leg of bench.py's cpu_baseline for cfg #3 / #4. */
+int oracle_wideband_parallel(const float* iq, uint64_t n, uint32_t proto, uint32_t access_addr,
+                             uint32_t crc_init, uint32_t threshold, uint32_t core, uint32_t warmup,
+                             uint64_t seg, snout_pkt* out, uint64_t cap, uint64_t* n_out)
+{
+    *n_out = 0;
+    const uint32_t M = proto == 0 ? 40u : 16u, D = M / 2u;
+    if (seg == 0 || seg % M) return -1;
+    const uint64_t overlap = (proto == 0 ? 1600ull : 17024ull + 2048ull) * D + 16ull * M;
+    const uint64_t ns = (n + seg - 1) / seg;
+    (void)oracle_fast_atan2f(0.0f, 1.0f);
+    uint64_t* cnt = (uint64_t*)calloc(ns ? ns : 1, sizeof(uint64_t));
+    snout_pkt** part = (snout_pkt**)calloc(ns ? ns : 1, sizeof(snout_pkt*));
+    if (!cnt || !part) { free(cnt); free(part); return -3; }
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t s = 0; s < (int64_t)ns; s++) {
+        const uint64_t a = (uint64_t)s * seg;
+        const uint64_t b = a + seg + overlap < n ? a + seg + overlap : n;
+        const uint64_t pc = (b - a) / 1024u + 256u;
+        snout_pkt* buf = (snout_pkt*)malloc((size_t)pc * sizeof(snout_pkt));
+        uint64_t got = 0;
+        int r = buf ? oracle_wideband_segment(iq + 2 * a, b - a, a / D, proto, access_addr, crc_init, threshold,
+                                              core, warmup, buf, pc, &got) : -3;
+        if (r) {
+#pragma omp critical
+            rc = r;
+        }
+        uint64_t keep = 0;
+        for (uint64_t i = 0; buf && i < got && i < pc; i++)
+            if (buf[i].sample_index < (a + seg) / D || (uint64_t)s + 1 == ns) buf[keep++] = buf[i];
+        part[s] = buf;
+        cnt[s] = keep;
+    }
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < ns; s++) {
+        for (uint64_t i = 0; i < cnt[s]; i++)
+            if (total + i < cap) out[total + i] = part[s][i];
+        total += cnt[s];
+        free(part[s]);
+    }
+    free(cnt);
+    free(part);
     *n_out = total;
     return rc ? rc : (total > cap ? -5 : 0);
 }

@@ -93,6 +93,16 @@ def lib() -> C.CDLL:
                                                  C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_void_p, C.c_uint64, u64p]
         _lib.oracle_wideband_segment.restype = C.c_int
+        _lib.oracle_set_threads.argtypes = [C.c_int]
+        _lib.oracle_set_threads.restype = C.c_int
+        _lib.oracle_hw_threads.restype = C.c_int
+        _lib.oracle_narrowband_parallel.argtypes = [f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        _lib.oracle_narrowband_parallel.restype = C.c_int
+        _lib.oracle_wideband_parallel.argtypes = [f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        _lib.oracle_wideband_parallel.restype = C.c_int
     return _lib
 
 
@@ -260,5 +270,46 @@ def wideband_segment(iq: np.ndarray, proto: int, first_sample_index: int = 0, aa
     rc = lib().oracle_wideband_segment(_p(a, C.c_float), n, first_sample_index, proto, aa, crc_init,
                                        threshold, core, warmup, out.ctypes.data_as(C.c_void_p), cap,
                                        C.byref(n_out))
+    assert rc == 0, rc
+    return out[:n_out.value]
+
+
+# ---- threads (bench.py cpu_baseline legs) ------------------------------------------------------------
+def set_threads(n: int) -> int:
+    """OpenMP threads used by oracle_pfb and the parallel receivers (1 = the scalar port)."""
+    return int(lib().oracle_set_threads(int(n)))
+
+
+def hw_threads() -> int:
+    return int(lib().oracle_hw_threads())
+
+
+def narrowband_parallel(iq: np.ndarray, proto: int, channel: int, seg: int = 1 << 22, overlap: int = 0,
+                        aa: int = 0x8E89BED6, crc_init: int = 0x555555, threshold: int = 10,
+                        core: int = 2048, warmup: int = 512, cap: int = 0) -> np.ndarray:
+    """Overlapping segments of one single-channel capture, one OpenMP task each (all-cores leg)."""
+    a = _f32(iq)
+    n = a.size // 2
+    overlap = overlap or (1600 if proto == 0 else 17024 + 2048)
+    cap = cap or max(256, n // 256)
+    out = np.zeros(cap, dtype=PKT_DTYPE)
+    n_out = C.c_uint64(0)
+    rc = lib().oracle_narrowband_parallel(_p(a, C.c_float), n, proto, channel, aa, crc_init, threshold,
+                                          core, warmup, seg, overlap, out.ctypes.data_as(C.c_void_p), cap,
+                                          C.byref(n_out))
+    assert rc == 0, rc
+    return out[:n_out.value]
+
+
+def wideband_parallel(iq: np.ndarray, proto: int, seg: int, aa: int = 0x8E89BED6, crc_init: int = 0x555555,
+                      threshold: int = 10, core: int = 2048, warmup: int = 512, cap: int = 0) -> np.ndarray:
+    """Overlapping segments of one wideband capture, one OpenMP task each (all-cores leg)."""
+    a = _f32(iq)
+    n = a.size // 2
+    cap = cap or max(256, n // 128)
+    out = np.zeros(cap, dtype=PKT_DTYPE)
+    n_out = C.c_uint64(0)
+    rc = lib().oracle_wideband_parallel(_p(a, C.c_float), n, proto, aa, crc_init, threshold, core, warmup,
+                                        seg, out.ctypes.data_as(C.c_void_p), cap, C.byref(n_out))
     assert rc == 0, rc
     return out[:n_out.value]

@@ -34,6 +34,7 @@
 namespace snout {
 
 struct cf { float re, im; };
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.re - b.re, a.im - b.im}; }
@@ -71,9 +72,8 @@ __device__ __forceinline__ void dft8(const cf a[8], cf X[8])
 }
 
 // 5-point DFT by its real-factor symmetry, the operation order of oracle_pfb.c.
-__device__ __forceinline__ void dft5(const cf b[5], cf X[5], const float* __restrict__ tw5)
+__device__ __forceinline__ void dft5(const cf b[5], cf X[5], const float C1, const float C2, const float S1, const float S2)
 {
-    const float C1 = tw5[2], C2 = tw5[4], S1 = -tw5[3], S2 = -tw5[5];
     const cf t1 = cadd(b[1], b[4]), t2 = cadd(b[2], b[3]), t3 = csub(b[1], b[4]), t4 = csub(b[2], b[3]);
     cf a1, a2, s1, s2;
     X[0] = cadd(cadd(b[0], t1), t2);
@@ -161,8 +161,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     constexpr int NPRE = NEW4 / NT;                // new pairs each thread stages per tile
     __shared__ float2 xs[SPAN];                    // input span of the current tile
     __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
-    __shared__ float tw_s[2 * M + 10];
     constexpr bool ZB = FUSED && M == 16;          // fused 802.15.4 discriminator epilogue
+#ifdef SNOUT_PFB_NO_FUSE3B
+    constexpr bool FUSE3B = false;
+#else
+    constexpr bool FUSE3B = FUSED && M == 40;      // BTLE: pass 3b decides the hard bits in registers
+#endif
     constexpr int DLROW = T + 1;                   // padded row of the tile's d values (S_j reads)
     static_assert(!ZB || (M * DLROW <= 2 * SPAN && T == 128 && NT == 256), "d tile reuses the input span");
     __shared__ float atan_s[ZB ? 257 : 1];
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     __shared__ float2 prevy[ZB ? M : 1];           // y[m0 - 1] of every channel
 
     const int t = threadIdx.x;
-    for (int i = t; i < 2 * M; i += NT) tw_s[i] = twM[i];
-    if (t < 10) tw_s[2 * M + t] = tw5g[t];
+    // 5-point DFT factors (kTw5): uniform loads, scalar registers
+    const float c5_1 = tw5g[2], c5_2 = tw5g[4], s5_1 = -tw5g[3], s5_2 = -tw5g[5];
     if constexpr (ZB) {
         for (int i = t; i < 257; i += NT) atan_s[i] = zb.atan_tab[i];
         if (t < 64) wts_s[t] = zb.iir_w[t];
@@ -182,6 +186,19 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     float h[P];
 #pragma unroll
     for (int p = 0; p < P; p++) h[p] = proto[r + p * M];
+
+    static_assert((T * M2) % NT == 0 && T % 64 == 0, "pass 3a: whole rounds, wave-uniform n2");
+    float tw3a[T * M2 / NT][2 * M1];               // W_M^{n2 k1} of this wave's n2 per round (scalar registers)
+#pragma unroll
+    for (int rnd = 0; rnd < T * M2 / NT; rnd++) {
+        const int n2u = __builtin_amdgcn_readfirstlane((t + rnd * NT) / T);
+#pragma unroll
+        for (int k1 = 0; k1 < M1; k1++) {
+            const int j = (n2u * k1) % M;          // < M: n2 k1 <= (M2-1)(M1-1) < M for both geometries
+            tw3a[rnd][2 * k1] = twM[2 * j];
+            tw3a[rnd][2 * k1 + 1] = twM[2 * j + 1];
+        }
+    }
 
     const uint32_t t_begin = blockIdx.x * tiles_per_wg;
     uint32_t t_end = t_begin + tiles_per_wg;
@@ -214,7 +231,15 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     float2 carry = make_float2(0.0f, 0.0f);        // y_k[m0 - 4 + j] of the previous tile
     uint32_t pend = 0;                             // its 15 decided bits
     bool have_prev = false;
+    cf carry5[FUSE3B ? M2 : 1];                    // FUSE3B: yB of the previous tile (the b = 7 threads use it)
+#pragma unroll
+    for (int i = 0; i < (FUSE3B ? M2 : 1); i++) carry5[i] = cf{0.0f, 0.0f};
 
+#ifdef SNOUT_PFB_STAGGER
+    // Workgroups that share a CU start together and would run their LDS-heavy and VALU-heavy phases
+    // in step; delay every other round of the grid by a fraction of a tile.
+    for (uint32_t i = 0; i < (blockIdx.x / 256u) % 3u; i++) __builtin_amdgcn_s_sleep(SNOUT_PFB_STAGGER);
+#endif
     for (uint32_t tile = t_first; tile < t_last; tile++) {
         const uint64_t m0 = (uint64_t)tile * T;
         // ---- 1. stage: overlap to the front, new samples behind it
@@ -237,8 +262,31 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         {
             const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
             float2 w[8 + P - 1];
+#ifdef SNOUT_PFB_NOREAD2
+            // one ds_read_b64 per window sample: the compiler pairs them into ds_read2_b64, which moves
+            // the same bytes at half the LDS rate (MI355X_MICROARCH.md, LDS table)
+            {
+                const uint32_t a0 = (uint32_t)(uintptr_t)&xs[base];
+                v2f wv[8 + P - 1];
+#pragma unroll
+                for (int q = 0; q < 8 + P - 1; q++)
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+                // the wait names every loaded register as an operand, so that no use can be scheduled ahead of it
+                static_assert(8 + P - 1 == 23, "operand list below");
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                               "+v"(wv[7]), "+v"(wv[8]), "+v"(wv[9]), "+v"(wv[10]), "+v"(wv[11]), "+v"(wv[12]),
+                               "+v"(wv[13]), "+v"(wv[14])
+                             :: "memory");
+                asm volatile("" : "+v"(wv[15]), "+v"(wv[16]), "+v"(wv[17]), "+v"(wv[18]), "+v"(wv[19]), "+v"(wv[20]),
+                                  "+v"(wv[21]), "+v"(wv[22]) :: "memory");
+#pragma unroll
+                for (int q = 0; q < 8 + P - 1; q++) w[q] = make_float2(wv[q].x, wv[q].y);
+            }
+#else
 #pragma unroll
             for (int q = 0; q < 8 + P - 1; q++) w[q] = xs[base + q * M];
+#endif
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 float ar = 0.0f, ai = 0.0f;
@@ -255,8 +303,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 
         // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}; in place:
         //      slot M2 k1 + n2 of row m receives B[n2][k1]
-        for (int it = t; it < T * M2; it += NT) {
-            const int m = it % T, n2 = it / T;
+#pragma unroll
+        for (int rnd = 0; rnd < T * M2 / NT; rnd++) {
+            // T is a multiple of 64, so n2 is the same for a whole wave: its twiddles W_M^{n2 k1} are
+            // wave-uniform values held in scalar registers (tw3a, loaded before the tile loop)
+            const int it = t + rnd * NT;
+            const int m = it % T, n2 = __builtin_amdgcn_readfirstlane(it / T);
             cf a[M1], A[M1];
 #pragma unroll
             for (int n1 = 0; n1 < M1; n1++) {
@@ -264,11 +316,16 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
                 a[n1] = cf{v.x, v.y};
             }
             if constexpr (M1 == 8) dft8(a, A); else dft4(a, A);
+            us[m * ROW + n2] = make_float2(A[0].re, A[0].im);           // k1 = 0: W^0
+            if (n2 == 0) {                                              // uniform: W^0 throughout
 #pragma unroll
-            for (int k1 = 0; k1 < M1; k1++) {
-                const int j = (n2 * k1) % M;
-                const cf v = j ? cmul_tw(A[k1], tw_s[2 * j], tw_s[2 * j + 1]) : A[k1];
-                us[m * ROW + M2 * k1 + n2] = make_float2(v.re, v.im);
+                for (int k1 = 1; k1 < M1; k1++) us[m * ROW + M2 * k1 + n2] = make_float2(A[k1].re, A[k1].im);
+            } else {
+#pragma unroll
+                for (int k1 = 1; k1 < M1; k1++) {
+                    const cf v = cmul_tw(A[k1], tw3a[rnd][2 * k1], tw3a[rnd][2 * k1 + 1]);
+                    us[m * ROW + M2 * k1 + n2] = make_float2(v.re, v.im);
+                }
             }
         }
         lds_barrier();
@@ -276,6 +333,73 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
         //      Fused: in place, channel k = k1 + M1 k2 ends up in slot M2 k1 + k2 of row m.
         //      Otherwise a thread owns two consecutive output times so each global store is 16 B.
+        if constexpr (FUSE3B) {
+            // ---- 3b + 4 fused (BTLE).  Thread <-> (phase a, symbol pair b, k1): the 5-point DFTs of the
+            //      output times mA = a + 8 b and mB = mA + 4, i.e. symbols 2b and 2b+1 of sampling phase a,
+            //      for the channels k = k1 + 8 k2.  bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m]) needs y[m] and
+            //      y[m+4] only, so symbol 2b is decided from this thread's own two results and symbol
+            //      2b+1 with yA of the thread 4 lanes up (ds_bpermute; the 32 threads of a k1 share half
+            //      a wave) -- the outputs never go back to LDS.  The factor (-1)^{km} is the same for m and
+            //      m+4 and cancels in both products exactly, so it is not applied.  The last symbol of a
+            //      tile (b = 7) has its partner in the next tile: the thread carries its yB in registers
+            //      and its bit is produced one tile later, in the same lane position.  The bits of the 64
+            //      lanes come out of v_cmp as a wave mask; lanes (k2, k1 half g, a) pick the 2 x 8 bits of
+            //      their channel and phase out of the masks and interleave them into the 16-bit quarter
+            //      of the plane word.
+            if (t < (T / 2) * M1) {
+                const int mp = t & 31, k1 = t >> 5, a = mp & 3, b = mp >> 2;
+                const int mA = a + 8 * b;
+                cf YA[M2], YB[M2];
+                {
+                    cf bb[M2];
+#pragma unroll
+                    for (int n2 = 0; n2 < M2; n2++) { const float2 v = us[mA * ROW + M2 * k1 + n2]; bb[n2] = cf{v.x, v.y}; }
+                    dft5(bb, YA, c5_1, c5_2, s5_1, s5_2);
+#pragma unroll
+                    for (int n2 = 0; n2 < M2; n2++) { const float2 v = us[(mA + 4) * ROW + M2 * k1 + n2]; bb[n2] = cf{v.x, v.y}; }
+                    dft5(bb, YB, c5_1, c5_2, s5_1, s5_2);
+                }
+                const int src = ((t & 32) | ((t + 4) & 31)) << 2;         // lane of (a, b + 1 mod 8, k1)
+                // lanes 0..39 of the wave: (k2s, g, j) -> channel k = (2 wave + g) + 8 k2s, phase j
+                const int L = t & 63, k2s = L >> 3, g = (L >> 2) & 1, j = L & 3;
+                uint64_t sa = 0, sb = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < M2; k2++) {
+                    const float pre_ = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(YA[k2].re)));
+                    const float pim_ = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(YA[k2].im)));
+                    const float ore = b == 7 ? carry5[k2].re : YB[k2].re;  // b = 7: yB of the previous tile
+                    const float oim = b == 7 ? carry5[k2].im : YB[k2].im;
+                    const uint64_t mA_ = __builtin_amdgcn_ballot_w64((YA[k2].re * YB[k2].im) > (YB[k2].re * YA[k2].im));
+                    const uint64_t mB_ = __builtin_amdgcn_ballot_w64((ore * pim_) > (pre_ * oim));
+                    if (k2s == k2) { sa = mA_; sb = mB_; }               // the lanes that assemble this k2
+                    carry5[k2] = YB[k2];
+                }
+                const uint32_t xa = (uint32_t)(sa >> (32 * g + j)) & 0x11111111u;     // bit 4b: symbol 2b
+                const uint32_t xb = (uint32_t)(sb >> (32 * g + j)) & 0x11111111u;     // bit 4b: symbol 2b+1 (b = 7: previous tile's 15)
+                uint32_t c = xa | (xb << 1);
+                c = (c | (c >> 2)) & 0x0F0F0F0Fu;
+                c = (c | (c >> 4)) & 0x00FF00FFu;
+                c = (c | (c >> 8)) & 0x0000FFFFu;                                     // bit l: symbol l
+                if (L < 8 * M2) {
+                    const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;              // bits exist for m < n_out-4
+                    const int k = 2 * (t >> 6) + g + M1 * k2s;
+                    if (have_prev) {
+                        const uint64_t mprev = m0 - 4u + (uint64_t)j;                // sample of the carried symbol
+                        const uint32_t b15 = (mprev < nbits) ? (c >> 15) : 0u;
+                        const uint64_t mq = m0 - (uint64_t)T;                        // first sample of the previous tile
+                        planes16[((uint64_t)k * plane_stride + (mq >> 8) * 4u + (uint32_t)j) * 4u +
+                                 (uint32_t)((mq & 255u) >> 6)] = (uint16_t)(pend | (b15 << 15));
+                    }
+                    const uint32_t left = nbits > m0 ? (uint32_t)(nbits - m0 < 64u ? nbits - m0 : 64u) : 0u;   // uniform
+                    const uint32_t cnt = left > (uint32_t)j ? (left - (uint32_t)j + 3u) >> 2 : 0u;
+                    pend = c & ((1u << (cnt < 15u ? cnt : 15u)) - 1u);
+                    if (tile + 1u == n_tiles)                                        // no later tile: symbol 15 has no partner
+                        planes16[((uint64_t)k * plane_stride + (m0 >> 8) * 4u + (uint32_t)j) * 4u +
+                                 (uint32_t)((m0 & 255u) >> 6)] = (uint16_t)pend;
+                }
+                have_prev = true;
+            }
+        } else
         for (int it = t; it < (T / 2) * M1; it += NT) {
             const int mp = it % (T / 2), k1 = it / (T / 2);
             cf Y0[M2], Y1[M2];
@@ -288,8 +412,8 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
                     const float2 v = us[m * ROW + M2 * k1 + n2];
                     b[n2] = cf{v.x, v.y};
                 }
-                if (h2 == 0) { if constexpr (M2 == 5) dft5(b, Y0, &tw_s[2 * M]); else dft4(b, Y0); }
-                else         { if constexpr (M2 == 5) dft5(b, Y1, &tw_s[2 * M]); else dft4(b, Y1); }
+                if (h2 == 0) { if constexpr (M2 == 5) dft5(b, Y0, c5_1, c5_2, s5_1, s5_2); else dft4(b, Y0); }
+                else         { if constexpr (M2 == 5) dft5(b, Y1, c5_1, c5_2, s5_1, s5_2); else dft4(b, Y1); }
             }
             const uint64_t mg = m0 + 2ull * (uint64_t)mp;        // even: only the odd time flips
 #pragma unroll
@@ -351,7 +475,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             lds_barrier();                                            // ... it writes xs first: wait for the S_j reads
         }
 
-        if constexpr (FUSED && M == 40) {
+        if constexpr (FUSED && M == 40 && !FUSE3B) {
             lds_barrier();
             // ---- 4. hard bits.  Thread <-> (channel k, phase j), samples m = 4 s + j: symbol 15 of
             //      the previous tile (its sample is carried in a register) completes that tile's

@@ -99,20 +99,84 @@ def gather_records(rec: np.ndarray, device=None, group=None) -> Optional[np.ndar
     return np.concatenate(parts)
 
 
+def wire_dtype(width: int) -> np.dtype:
+    """Record layout on the wire: the first ``width`` bytes of a 160-byte ``snout_pkt``."""
+    return np.dtype([("sample_index", "<u8"), ("proto", "<u4"), ("channel", "<u2"),
+                     ("len", "<u2"), ("crc_ok", "u1"), ("lqi", "u1"), ("pdu_type", "u1"),
+                     ("flags", "u1"), ("aux", "<u4"), ("bytes", "u1", (width - 24,))])
+
+
+def widen_records(rec: np.ndarray) -> np.ndarray:
+    """Wire records (any width) -> full 160-byte ``PKT_DTYPE`` records (zero padded)."""
+    if rec.dtype == PKT_DTYPE:
+        return rec
+    out = np.zeros(rec.size, dtype=PKT_DTYPE)
+    for f in ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags", "aux"):
+        out[f] = rec[f]
+    out["bytes"][:, :rec["bytes"].shape[1]] = rec["bytes"]
+    return out
+
+
+_DROP = np.uint64(1) << np.uint64(62)      # sample_index of a record an append() disowned
+
+
+def dedup_device(torch, rows, counts, cap: int, tol: int):
+    """Fixed-shape sort + duplicate removal of gathered wire records on the device they sit on
+    (no host synchronisation, so it can be queued on a side stream behind the all_gather).
+
+    rows:   int64 [world * cap, width / 8]: the record slots of every rank, rank-major
+    counts: int64 [world]: the valid prefix of every rank's block
+    Returns (out int64 [world*cap + 1, width/8], n_keep int64 [1]): the kept records, sorted by
+    (proto, channel, sample_index), in out[:n_keep].  Same rule as :func:`dedup_records`."""
+    world = counts.numel()
+    R = world * cap
+    slot = torch.arange(cap, device=rows.device).repeat(world)
+    valid = slot < counts.repeat_interleave(cap)
+    si = rows[:, 0]
+    valid &= si < int(_DROP)
+    meta = rows[:, 1]                                           # proto | channel << 32 | len << 48
+    key = ((meta & 0xF) << 60) | (((meta >> 32) & 0xFFFF) << 44) | (si & ((1 << 44) - 1))
+    key = torch.where(valid, key, torch.full_like(key, (1 << 63) - 1))
+    sk, order = torch.sort(key, stable=True)
+    srt = rows.index_select(0, order)
+    ok = sk != (1 << 63) - 1
+    dup = torch.zeros(R, dtype=torch.bool, device=rows.device)
+    if R > 1:
+        near = ((sk[1:] >> 44) == (sk[:-1] >> 44)) & ((sk[1:] - sk[:-1]) <= tol) & ok[1:]
+        if tol > 0:         # same frame only if length and bytes agree (dedup_records)
+            near &= (srt[1:, 1] == srt[:-1, 1]) & (srt[1:, 3:] == srt[:-1, 3:]).all(dim=1)
+        dup[1:] = near
+    keep = ok & ~dup
+    pos = torch.cumsum(keep, 0) - 1
+    idx = torch.where(keep, pos, torch.full_like(pos, R))       # dropped rows land in the spare slot
+    out = torch.empty((R + 1, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    out.index_copy_(0, idx, srt)
+    return out, keep.sum().reshape(1)
+
+
 class AsyncRecordGather:
     """Pipelined gather of packet records to rank 0.
 
-    ``start(rec)`` enqueues, on a side stream, the upload of this rank's records, ONE fixed-size
-    ``all_gather`` (RCCL over xGMI with the nccl backend) and, on rank 0, the download of the
-    gathered block into pinned host memory; ``finish()`` waits for the oldest started gather and
-    returns the records (rank 0) or None.  Two gathers may be in flight, so the exchange of step i
-    overlaps the kernels of step i+1.  Every rank sends ``cap`` record slots preceded by a header
-    slot holding its count; ``cap`` is agreed once, at the first start(): 1.25x the largest count of
-    any rank + 1024 (traffic of a capture is stationary; a rank that later exceeds it raises).  ``width`` < 160 gathers only the first ``width`` bytes of each record
-    (BTLE records use at most 24 + 42 bytes; the rest is zero by construction).
+    One exchange = ``begin()``, any number of ``append()`` (one per collected segment), ``launch()``;
+    ``start(rec, dev_ptr)`` is the three in one.  ``launch()`` enqueues, on a side stream, ONE
+    fixed-size ``all_gather`` (RCCL over xGMI with the nccl backend) and, on rank 0, an optional
+    device-side sort + dedup of the gathered block (``dedup_tol`` not None) and its download into
+    pinned host memory; ``finish()`` waits for the oldest launched exchange and returns the records
+    (rank 0) or None.  Two exchanges may be in flight, so the exchange of step i overlaps the
+    kernels of step i+1.
+
+    Every rank sends ``cap`` record slots preceded by a header slot holding its TRUE count.  A rank
+    with more records than slots sends what fits and keeps the rest; since every rank sees every
+    header, all ranks find out together in ``finish()``, exchange the remainders in a second
+    (synchronous) all_gather and raise the capacity for the exchanges that follow -- overflow is a
+    collective decision, never one rank raising while the others sit in the collective.
+
+    ``width`` < 160 gathers only the first ``width`` bytes of each record (BTLE records use at most
+    24 + 42 bytes; the rest is zero by construction); a record that does not fit is a ValueError.
     """
 
-    def __init__(self, device=None, group=None, width: int = REC):
+    def __init__(self, device=None, group=None, width: int = REC, dedup_tol: Optional[int] = None,
+                 cap: int = 0):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -120,116 +184,195 @@ class AsyncRecordGather:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
-        self.on_gpu = self.backend == "nccl"
-        self.device = device if self.on_gpu else torch.device("cpu")
+        self.on_gpu = self.backend == "nccl" or (self.backend == "none" and device is not None
+                                                 and torch.device(device).type == "cuda")
+        self.device = torch.device(device) if self.on_gpu else torch.device("cpu")
         self.width = int(width)
         assert 24 < self.width <= REC and self.width % 8 == 0
-        self.cap = 0
-        self.slots = []
+        self.dedup_tol = dedup_tol
+        self.cap = int(cap)             # capacity new exchanges are sized for (0: agreed at the first launch)
+        self.slots = [None, None]
+        self.next = 0
+        self.cur = None
         self.inflight = []
         # high priority: the short exchange must not queue behind the next segment's kernels
-        self.stream = torch.cuda.Stream(device=device, priority=-1) if self.on_gpu else None
-        self.dtype = np.dtype([("sample_index", "<u8"), ("proto", "<u4"), ("channel", "<u2"),
-                               ("len", "<u2"), ("crc_ok", "u1"), ("lqi", "u1"), ("pdu_type", "u1"),
-                               ("flags", "u1"), ("aux", "<u4"), ("bytes", "u1", (self.width - 24,))])
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1) if self.on_gpu else None
+        self.dtype = wire_dtype(self.width)
 
-    def _agree_cap(self, n: int):
+    # ---- buffers -------------------------------------------------------------------------------
+    def _make_slot(self, cap: int) -> dict:
+        torch = self.torch
+        W, pin = self.width, self.on_gpu
+        send = torch.zeros((cap + 1) * W, dtype=torch.uint8, device=self.device)
+        recv = torch.zeros(self.world * (cap + 1) * W, dtype=torch.uint8, device=self.device)
+        hdr = torch.zeros(self.world, dtype=torch.int64, pin_memory=pin)
+        host = n_host = None
+        if self.rank == 0:
+            rows = self.world * cap + 1 if self.dedup_tol is not None else self.world * (cap + 1)
+            host = torch.zeros(rows * W, dtype=torch.uint8, pin_memory=pin)
+            n_host = torch.zeros(1, dtype=torch.int64, pin_memory=pin)
+        ev = torch.cuda.Event() if self.on_gpu else None
+        up = torch.cuda.Event() if self.on_gpu else None
+        return dict(cap=cap, send=send, recv=recv, hdr=hdr, host=host, n_host=n_host, ev=ev, up=up,
+                    fill=0, n=0, rest=[])
+
+    def _agree(self, n: int) -> int:
         t = self.torch.tensor([n], dtype=self.torch.int64, device=self.device)
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        self.cap = int(t.item()) + int(t.item()) // 4 + 1024
-        torch = self.torch
-        self.slots = []
-        for _ in range(2):
-            send = torch.zeros((self.cap + 1) * self.width, dtype=torch.uint8, device=self.device)
-            # full 160-byte records land here first (one contiguous copy); the first `width` bytes
-            # of each are then packed into `send` on the device
-            stage = torch.zeros(self.cap * REC, dtype=torch.uint8, device=self.device) \
-                if (self.on_gpu and self.width < REC) else None
-            recv = torch.zeros(self.world * (self.cap + 1) * self.width, dtype=torch.uint8,
-                               device=self.device)
-            host = torch.zeros(recv.shape, dtype=torch.uint8,
-                               pin_memory=self.on_gpu) if self.rank == 0 else None
-            ev = torch.cuda.Event() if self.on_gpu else None
-            up = torch.cuda.Event() if self.on_gpu else None
-            self.slots.append(dict(send=send, recv=recv, host=host, ev=ev, up=up, stage=stage))
-        self.next = 0
+        return int(t.item())
 
-    def start(self, rec: np.ndarray, dev_ptr: int = 0) -> None:
-        """``dev_ptr``: device address of the same records (SnoutRx.last_records_device()); with the
-        nccl backend they are then packed straight from device memory, no upload."""
-        torch = self.torch
-        n = int(rec.size)
-        while len(self.inflight) >= 2:
+    def _ctx(self):
+        return self.torch.cuda.stream(self.stream) if self.on_gpu else _null_ctx()
+
+    # ---- one exchange --------------------------------------------------------------------------
+    def begin(self, n_hint: int = 0) -> None:
+        """Open an exchange.  The first one agrees the capacity (collective: 1.25x the largest
+        ``n_hint`` of any rank + 1024); later ones reuse or grow their slot without a collective."""
+        if len(self.inflight) >= 2:
             raise RuntimeError("two gathers in flight: finish() one first")
-        if not self.slots:
-            self._agree_cap(n)      # collective: every rank makes its first start() together
-        if n > self.cap:
-            # re-agreeing is a collective every rank would have to enter at the same step
-            raise RuntimeError(f"rank {self.rank}: {n} records exceed the agreed gather capacity "
-                               f"{self.cap} (1.25x the largest first-step count + 1024)")
-        slot = self.slots[self.next]
+        assert self.cur is None, "launch() the open exchange first"
+        if self.cap == 0:
+            m = self._agree(int(n_hint))
+            self.cap = m + m // 4 + 1024
+        k = self.next
         self.next ^= 1
-        hdr = np.zeros(self.width, dtype=np.uint8)
-        hdr[:8] = np.frombuffer(np.uint64(n).tobytes(), dtype=np.uint8)
-        raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1) if n else None    # n x 160 bytes, a view
-        # No dependency on the caller's stream: the records are host memory that collect() has
-        # already waited for, and the slot's buffers were released by the finish() of its last use.
-        # (Waiting for the current stream would queue the exchange behind the front-end kernels of
-        # the segments submitted since.)
-        ctx = torch.cuda.stream(self.stream) if self.on_gpu else _null_ctx()
-        with ctx:
-            send = slot["send"]
-            send[:self.width].copy_(torch.from_numpy(hdr), non_blocking=True)
-            if n:
-                view = send[self.width:(n + 1) * self.width].view(n, self.width)
-                if self.on_gpu and dev_ptr:
-                    dev = _device_bytes(torch, dev_ptr, n * REC, self.device)
-                    view.copy_(dev.view(n, REC)[:, :self.width])
-                elif slot["stage"] is not None:
-                    # contiguous upload (a strided host-side gather of 52 k records costs ~8 ms), then
-                    # the narrowing copy as a device kernel
-                    st = slot["stage"][:n * REC]
-                    st.copy_(torch.from_numpy(raw), non_blocking=True)
-                    view.copy_(st.view(n, REC)[:, :self.width])
-                else:
-                    view.copy_(torch.from_numpy(raw.reshape(n, REC)[:, :self.width]), non_blocking=True)
-            if self.on_gpu:
-                slot["up"].record(self.stream)       # the caller's record buffer may be reused after this
-            if self.world > 1:
-                self.dist.all_gather_into_tensor(slot["recv"], send, group=self.group)
+        if self.slots[k] is None or self.slots[k]["cap"] < self.cap:
+            self.slots[k] = self._make_slot(self.cap)
+        slot = self.slots[k]
+        slot["fill"], slot["n"], slot["rest"] = 0, 0, []
+        self.cur = slot
+
+    def append(self, rec: np.ndarray, dev_ptr: int = 0, own_from: int = 0) -> None:
+        """Add the records of one collected segment.  ``dev_ptr``: device address of the same records
+        (SnoutRx.last_records_device()); on a GPU they are then packed straight from device memory.
+        Records with sample_index < ``own_from`` belong to another segment and are dropped."""
+        torch = self.torch
+        slot = self.cur
+        n = int(rec.size)
+        if n == 0:
+            return
+        if int(rec["len"].max()) > self.width - 24:
+            raise ValueError(f"record of {int(rec['len'].max())} bytes does not fit the {self.width}-byte wire format")
+        W = self.width
+        slot["n"] += n
+        take = min(n, slot["cap"] - slot["fill"])
+        if take < n:                                    # keeps its true count in the header; finish() resends
+            r = np.ascontiguousarray(rec[take:]).copy()
+            if own_from:
+                r = r[r["sample_index"] >= own_from]
+                slot["n"] -= (n - take) - r.size
+            slot["rest"].append(r)
+        if take == 0:
+            return
+        with self._ctx():
+            view = slot["send"][(1 + slot["fill"]) * W:(1 + slot["fill"] + take) * W].view(take, W)
+            if self.on_gpu and dev_ptr:
+                view.copy_(_device_bytes(torch, dev_ptr, take * REC, self.device).view(take, REC)[:, :W])
             else:
-                slot["recv"].copy_(send)
+                raw = np.ascontiguousarray(rec[:take]).view(np.uint8).reshape(take, REC)
+                if self.on_gpu:     # contiguous upload, then the narrowing copy as a device kernel
+                    view.copy_(torch.from_numpy(raw.copy()).to(self.device, non_blocking=True)[:, :W])
+                else:
+                    view.copy_(torch.from_numpy(raw[:, :W].copy()))
+            if own_from:
+                si = view.view(torch.int64)[:, 0]       # disowned records sort last and are not counted
+                si.copy_(torch.where(si < own_from, torch.full_like(si, int(_DROP)), si))
+        slot["fill"] += take
+
+    def launch(self) -> None:
+        torch = self.torch
+        slot = self.cur
+        self.cur = None
+        W, cap = self.width, slot["cap"]
+        with self._ctx():
+            hdr = np.zeros(W, dtype=np.uint8)
+            hdr[:8] = np.frombuffer(np.uint64(slot["n"]).tobytes(), dtype=np.uint8)
+            slot["send"][:W].copy_(torch.from_numpy(hdr), non_blocking=True)
+            if self.on_gpu:
+                slot["up"].record(self.stream)       # the callers' record buffers may be reused after this
+            if self.world > 1:
+                self.dist.all_gather_into_tensor(slot["recv"], slot["send"], group=self.group)
+            else:
+                slot["recv"].copy_(slot["send"])
+            blocks = slot["recv"].view(self.world, (cap + 1) * W)
+            counts = blocks[:, :8].contiguous().view(torch.int64).reshape(self.world)
+            slot["hdr"].copy_(counts, non_blocking=True)         # every rank learns every count
             if self.rank == 0:
-                slot["host"].copy_(slot["recv"], non_blocking=True)
+                if self.dedup_tol is not None:
+                    rows = blocks[:, W:].reshape(self.world * cap, W).view(torch.int64)
+                    out, n_keep = dedup_device(torch, rows, torch.clamp(counts, max=cap), cap, int(self.dedup_tol))
+                    slot["host"].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
+                    slot["n_host"].copy_(n_keep, non_blocking=True)
+                else:
+                    slot["host"].copy_(slot["recv"], non_blocking=True)
             if self.on_gpu:
                 slot["ev"].record(self.stream)
         self.inflight.append(slot)
 
+    def start(self, rec: np.ndarray, dev_ptr: int = 0) -> None:
+        """One segment = one exchange: begin + append + launch."""
+        self.begin(int(rec.size))
+        self.append(rec, dev_ptr)
+        self.launch()
+
     def sync_uploads(self) -> None:
-        """Block until the record buffers handed to start() have been read (they may be views of
+        """Block until the record buffers handed to append() have been read (they may be views of
         a receiver's pinned result slot that the next submit will overwrite)."""
         if self.on_gpu:
             for slot in self.inflight:
                 slot["up"].synchronize()
 
+    def _exchange_rest(self, slot, counts) -> Optional[np.ndarray]:
+        """Second, synchronous all_gather of what did not fit (every rank enters it: they all saw the
+        same headers).  Returns the remainder records on rank 0."""
+        torch = self.torch
+        W, cap = self.width, slot["cap"]
+        over = int(max(counts)) - cap
+        mine = np.concatenate(slot["rest"]) if slot["rest"] else np.zeros(0, dtype=PKT_DTYPE)
+        send = torch.zeros(over * W, dtype=torch.uint8)
+        if mine.size:
+            raw = np.ascontiguousarray(mine).view(np.uint8).reshape(mine.size, REC)[:, :W]
+            send[:mine.size * W] = torch.from_numpy(raw.copy().reshape(-1))
+        send = send.to(self.device)
+        recv = torch.zeros(self.world * over * W, dtype=torch.uint8, device=self.device)
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        else:
+            recv.copy_(send)
+        self.cap = max(self.cap, int(max(counts)) + int(max(counts)) // 4 + 1024)     # same on every rank
+        if self.rank != 0:
+            return None
+        host = recv.cpu().numpy().reshape(self.world, over * W)
+        parts = [host[r, :max(0, int(counts[r]) - cap) * W].view(self.dtype) for r in range(self.world)]
+        return np.concatenate(parts)
+
     def finish(self, views: bool = False):
-        """Records of the oldest started gather (rank 0; None elsewhere).  ``views=True`` returns a
-        list with one zero-copy view per rank into the pinned receive buffer (valid until the slot
-        is reused two start() calls later) instead of one concatenated array -- at 8 ranks the
-        concatenation is a 30 MB host copy per step."""
+        """Records of the oldest launched exchange (rank 0; None elsewhere), in the wire dtype
+        (:func:`widen_records` pads them back to ``PKT_DTYPE``).  With ``dedup_tol`` set: one sorted,
+        duplicate-free array.  Otherwise ``views=True`` returns a list with one zero-copy view per
+        rank into the pinned receive buffer (valid until the slot is reused two launches later)
+        instead of one concatenated array -- at 8 ranks the concatenation is a 30 MB host copy."""
         if not self.inflight:
             return None
         slot = self.inflight.pop(0)
         if self.on_gpu:
             slot["ev"].synchronize()
+        W, cap = self.width, slot["cap"]
+        counts = [int(c) for c in slot["hdr"].numpy()]
+        rest = self._exchange_rest(slot, counts) if max(counts) > cap else None
         if self.rank != 0:
             return None
-        host = slot["host"].numpy().reshape(self.world, (self.cap + 1) * self.width)
-        parts = []
-        for r in range(self.world):
-            n = int(host[r, :8].view("<u8")[0])
-            parts.append(host[r, self.width:(n + 1) * self.width].view(self.dtype))
+        if self.dedup_tol is not None:
+            n = int(slot["n_host"].item())
+            out = slot["host"].numpy()[:n * W].view(self.dtype)
+            if rest is not None:        # rare: merge the remainder with the host rule
+                out = dedup_records(np.concatenate([out, rest]), tol=int(self.dedup_tol))
+            return [out] if views else out.copy()     # a view is valid until the slot is reused two launches later
+        host = slot["host"].numpy().reshape(self.world, (cap + 1) * W)
+        parts = [host[r, W:(min(counts[r], cap) + 1) * W].view(self.dtype) for r in range(self.world)]
+        if rest is not None:
+            parts.append(rest)
         if views:
             return parts
         return np.concatenate(parts)

@@ -59,7 +59,10 @@ class ShardedScan:
         return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world, self.preroll)
 
     # ---- a scan as a sequence of steps, so that several scans can share a GPU (run_concurrent)
-    def start(self, n_total: int, source: Callable[[int, int], "object"], group=None) -> None:
+    def start(self, n_total: int, source: Callable[[int, int], "object"], group=None, sink=None) -> None:
+        """``sink``: an :class:`snout_amd.dist.AsyncRecordGather` with an open exchange; every collected
+        segment's records are then appended to it straight from device memory (no host concatenation)
+        instead of being kept in ``_parts``."""
         import torch
         if self._streams is None:
             dev = torch.device("cuda", torch.cuda.current_device())
@@ -76,6 +79,8 @@ class ShardedScan:
         self._own_from = [((rank + j * world) * self.seg_len) // self.decim if (rank + j * world) else 0
                           for j in range(len(self._segs))]
         self._source = source
+        self._sink = sink
+        self._appended = [None] * len(self.rxs)     # event behind the last device-side append of each handle
         self._next = 0                  # next segment to submit
         self._done = 0                  # segments collected
         self._alive = {}                # segment index -> tensor (kept until collected)
@@ -92,6 +97,10 @@ class ShardedScan:
             j = self._next
             a, b = self._segs[j]
             st = self._streams[j % H]
+            if self._appended[j % H] is not None:
+                # the result slot this submit reuses may still be being read by the sink's copy
+                st.wait_event(self._appended[j % H])
+                self._appended[j % H] = None
             with torch.cuda.stream(st):
                 x = self._source(a, b)
                 self.rxs[j % H].submit(x, first_sample_index=a // self.decim, stream=st.cuda_stream)
@@ -99,10 +108,20 @@ class ShardedScan:
             self._next += 1
         elif self._done < self._next:
             j = self._done
-            rec = self.rxs[j % H].collect()                     # segments of a handle complete in order
-            if self.preroll and self._own_from[j]:
-                rec = rec[rec["sample_index"] >= self._own_from[j]]
-            self._parts.append(rec)
+            rx = self.rxs[j % H]
+            own = self._own_from[j] if self.preroll else 0
+            if self._sink is not None:
+                rec = rx.collect(copy=False)                    # segments of a handle complete in order
+                self._sink.append(rec, rx.last_records_device()[0], own_from=own)
+                if self._sink.on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(self._sink.stream)
+                    self._appended[j % H] = ev
+            else:
+                rec = rx.collect()
+                if own:
+                    rec = rec[rec["sample_index"] >= own]
+                self._parts.append(rec)
             del self._alive[j]
             self._done += 1
 
@@ -130,6 +149,14 @@ class ShardedScan:
         if stats is not None:
             stats["device_s"], stats["post_s"] = t1 - t0, time.perf_counter() - t1
         return out
+
+
+def pump(scans) -> None:
+    """Drive started scans to completion, taking turns (see run_concurrent)."""
+    while any(sc.active() for sc in scans):
+        for sc in scans:
+            if sc.active():
+                sc.step()
 
 
 def run_concurrent(scans, n_totals, sources, group=None, gather_device=None, stats: Optional[dict] = None):

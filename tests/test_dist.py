@@ -143,3 +143,104 @@ def test_dedup_records_matches_the_three_key_definition():
         for tol in (0, 520):
             assert np.array_equal(dedup_records(allrec.copy(), tol=tol), reference(allrec, tol)), (base, tol)
     assert dedup_records(np.zeros(0, dtype=PKT_DTYPE)).size == 0
+
+
+def _worker_overflow(rank, world, port, q):
+    """A rank that outgrows the agreed capacity must not leave the others in the collective: every
+    rank learns the true counts from the gathered headers, and the remainder travels in a second
+    all_gather that all ranks enter together (overflow is a collective decision)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for dedup in (None, 0):
+            g = sdist.AsyncRecordGather(width=80, dedup_tol=dedup)
+            outs = []
+            sizes = [(3, 5), (4000, 7), (6, 3000), (5000, 5200)]       # (rank 0, rank 1) records per step
+            for step, sz in enumerate(sizes):
+                r = _recs([(0, 37 + rank, 100000 * step + i) for i in range(sz[rank])])
+                if len(g.inflight) == 2:
+                    outs.append(g.finish())
+                g.start(r)
+            while g.inflight:
+                outs.append(g.finish())
+            if rank == 0:
+                q.put((dedup, [(len(o), sorted(set(o["channel"].tolist())),
+                               int(o["sample_index"].min()), int(o["sample_index"].max())) for o in outs], g.cap))
+            else:
+                assert all(o is None for o in outs)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_overflow_is_a_collective_decision_gloo_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overflow, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180), q.get(timeout=180)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sizes = [(3, 5), (4000, 7), (6, 3000), (5000, 5200)]
+    for dedup, outs, cap in res:
+        assert len(outs) == 4
+        for step, (n, chans, lo, hi) in enumerate(outs):
+            assert n == sum(sizes[step]) and chans == [37, 38], (dedup, step, n)
+            assert lo == 100000 * step and hi == 100000 * step + max(sizes[step]) - 1
+        assert cap >= 5200                         # the capacity grew with the traffic, on every rank alike
+
+
+def test_device_dedup_equals_host_dedup():
+    """dedup_device (fixed-shape torch ops, what rank 0 runs on its GPU behind the all_gather) keeps
+    exactly the records dedup_records keeps, for the BTLE (exact) and 802.15.4 (tolerance) rules."""
+    import torch
+    rng = np.random.default_rng(9)
+    for width, tol in ((80, 0), (160, 520)):
+        world, cap = 3, 700
+        dt = sdist.wire_dtype(width)
+        blocks = np.zeros((world, cap), dtype=dt)
+        counts = [650, 0, 333]
+        full = []
+        for r in range(world):
+            n = counts[r]
+            b = blocks[r]
+            b["proto"][:n] = rng.integers(0, 2, n)
+            b["channel"][:n] = rng.integers(0, 5, n)
+            b["sample_index"][:n] = rng.integers(0, 40000, n)
+            b["len"][:n] = rng.integers(5, 30, n)
+            b["bytes"][:n, :6] = rng.integers(0, 4, (n, 6))
+            b["sample_index"][n:] = 7                       # garbage behind the valid prefix is ignored
+            if r == 2:                                      # near-duplicates of rank 0's records
+                b[:200] = blocks[0][:200]
+                b["sample_index"][:200] += rng.integers(0, 3, 200).astype(np.uint64) * (260 if tol else 0)
+            full.append(b[:n])
+        blocks[0]["sample_index"][5] = int(sdist._DROP)     # a record its segment disowned
+        want_in = np.concatenate(full)
+        want_in = want_in[want_in["sample_index"] < int(sdist._DROP)]
+        want = sdist.dedup_records(sdist.widen_records(want_in), tol=tol)
+        rows = torch.from_numpy(blocks.view(np.uint8).reshape(world * cap, width).copy()).view(torch.int64)
+        out, n_keep = sdist.dedup_device(torch, rows, torch.tensor(counts, dtype=torch.int64), cap, tol)
+        got = out.numpy().view(np.uint8).reshape(-1, width)[:int(n_keep)].copy().view(dt).reshape(-1)
+        got = sdist.widen_records(got)
+        assert len(got) == len(want)
+        for f in ("proto", "channel", "sample_index", "len"):
+            assert np.array_equal(got[f], want[f]), (width, f)
+        assert np.array_equal(got["bytes"], want["bytes"])
+
+
+def test_gather_rejects_records_wider_than_the_wire_format():
+    g = sdist.AsyncRecordGather(width=80)
+    r = _recs([(1, 11, 5)])
+    r["len"] = 100
+    g.begin(1)
+    with pytest.raises(ValueError):
+        g.append(r)
