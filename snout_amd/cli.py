@@ -1,9 +1,12 @@
 """`snout {btle,zigbee} scan` — the CLI surface of the reference (snout/cli.py:41-56,220-261) for the
-receive path: same option names (-c channels, -n packets, -t timeout, -f filename), samples taken
-from a recorded cf32 file (--iq) or a synthetic capture (--synthetic) instead of a live SDR.
+receive path: same option names and grammar (-c/--channels, -a/--active, -n/--num, -t/--timeout), samples
+taken from a recorded capture file (--iq) or a synthetic capture (--synthetic) instead of a live SDR.
+`--wideband` / `--sharded` receive every channel of a whole-band capture at once (one or several GPUs).
 
-`snout-rx btle-rx -c 37 -a 8e89bed6 -k 555555 --iq FILE` prints btle_rx-format lines on stdout, so
-an unmodified ``PController("btle_rx")`` (snout/util/btle.py:53) can drive it.
+Console entries (setup.py): `snout` = this group, as the reference's (setup.py:52-54); `btle_rx` prints
+btle_rx-format lines for `-c 37 -g 6 -a 8e89bed6 -k 555555 --iq FILE`, so an unmodified
+``PController("btle_rx")`` (snout/util/btle.py:53) can drive it.  In-tree: `bin/snout`, `bin/btle_rx`,
+`python -m snout_amd`.
 """
 from __future__ import annotations
 
@@ -12,27 +15,62 @@ import sys
 import click
 
 from . import synth
-from .scan import ArraySource, BtleScan, FileSource, ZigbeeScan
+from .scan import ArraySource, BtleScan, FileSource, WidebandSource, ZigbeeScan
 
 DEFAULTS = {"btle": dict(channels=(0, 39), default=37, timeout=10),      # snout/util/__init__.py:4-17
             "zigbee": dict(channels=(11, 26), default=11, timeout=10)}
 
 
-def parse_channels(spec: str, proto: str):
-    """'37', '37,38,39', '11:26' (inclusive range) — snout/util/iot_click.py:46-92."""
+def parse_channels(spec, proto: str):
+    """The grammar of the reference's ``ChannelsOption`` + ``get_channels``
+    (snout/util/iot_click.py:46-92, snout/cli.py:139-183): ``all`` -> every channel of the protocol;
+    ``a-b`` / ``a:b`` -> the inclusive range; a Python literal list / tuple (``[11,12,13]``, ``37,38``)
+    -> those channels as given (a one-element list is doubled, as upstream does); an int -> that
+    channel; nothing -> the protocol's default channel (the reference prompts for it).  Channels
+    outside the protocol's range are refused (the reference prints the range and exits)."""
+    import ast
     lo, hi = DEFAULTS[proto]["channels"]
-    out = []
-    for part in str(spec).split(","):
-        part = part.strip()
-        if ":" in part:
-            a, b = part.split(":")
-            out.extend(range(int(a), int(b) + 1))
-        elif part:
-            out.append(int(part))
-    for c in out:
-        if not lo <= c <= hi:
-            raise click.BadParameter(f"channel {c} outside {lo}..{hi} for {proto}")
-    return out or [DEFAULTS[proto]["default"]]
+    value = None if spec is None else str(spec).strip()
+    try:
+        if not value:
+            out = [DEFAULTS[proto]["default"]]
+        elif value.lower() == "all":
+            out = list(range(lo, hi + 1))
+        elif "-" in value or ":" in value:
+            a, b = value.split("-" if "-" in value else ":")
+            out = list(range(int(a), int(b) + 1))
+        else:
+            v = ast.literal_eval(value)
+            if isinstance(v, (list, tuple)):
+                out = [int(c) for c in v]
+                if len(out) == 1:
+                    out = out * 2               # upstream: value.extend(value)
+            elif isinstance(v, (int, float)):
+                out = [int(v)]
+            else:
+                raise ValueError(value)
+    except (ValueError, SyntaxError, TypeError):
+        raise click.BadParameter(f"channels {spec!r}: int (11), inclusive range (11:26), list ([11,12,13]) or all")
+    if not out or out[0] < lo or out[-1] > hi or any(not lo <= c <= hi for c in out):
+        raise click.BadParameter(f"Channels for the {proto} protocol must be in the range of [{lo}, {hi}]")
+    return out
+
+
+def stop_conditions(proto: str, num, timeout):
+    """snout/cli.py:246-250: at least one stop condition.  The reference prompts for both when neither
+    -n nor -t is given ("Packet Threshold (leave empty to disable)", "Decode Timeout (positive int)",
+    default snout/util/__init__.py:4-9); without a terminal the prompts' defaults apply."""
+    if num is not None and num < 0:
+        raise click.BadOptionUsage("num", "--num INT : int must be >= 0")
+    if num is None and timeout is None:
+        if sys.stdin is not None and sys.stdin.isatty():
+            v = click.prompt("Packet Threshold (leave empty to disable)", default="", show_default=False)
+            num = int(v) if str(v).strip() else None
+            timeout = float(click.prompt("Decode Timeout (positive int)", type=click.INT,
+                                         default=DEFAULTS[proto]["timeout"]))
+        else:
+            timeout = float(DEFAULTS[proto]["timeout"])
+    return (num or None), timeout
 
 
 @click.group()
@@ -43,7 +81,18 @@ def main():
 FORMATS = {"cf32": 0, "sc8": 1, "sc16": 2}
 
 
-def _source(proto, iq, synthetic, channels, seconds, fmt="cf32"):
+def _source(proto, iq, synthetic, channels, seconds, fmt="cf32", wideband=False, sharded=False, segment=1 << 24):
+    if wideband or sharded:
+        pid = 0 if proto == "btle" else 1
+        if iq:
+            return WidebandSource(iq, pid, FORMATS[fmt], segment=segment, sharded=sharded)
+        if not synthetic:
+            raise click.UsageError("give --iq FILE or --synthetic (no live SDR in this build)")
+        M = 40 if pid == 0 else 16
+        x, _ = synth.wideband_capture(pid, int(seconds * M * 2e6) // M * M, seed=3 + pid)
+        if fmt != "cf32":
+            x = synth.quantize(x, FORMATS[fmt]).reshape(-1, 2)
+        return WidebandSource(x, pid, FORMATS[fmt], segment=segment, sharded=sharded)
     if iq:
         return FileSource(iq, FORMATS[fmt])
     if not synthetic:
@@ -55,9 +104,19 @@ def _source(proto, iq, synthetic, channels, seconds, fmt="cf32"):
 
 def _scan_options(f):
     for opt in reversed([
-        click.option("-c", "--channels", default=None, help="e.g. 37 | 37,38 | 11:26"),
-        click.option("-n", "--packets", type=int, default=None, help="stop after N packets"),
-        click.option("-t", "--timeout", type=float, default=None, help="seconds of capture per channel"),
+        click.option("-c", "--channels", default=None,
+                     help="Specify the channels. Int (11), inclusive range (11:26), list ([11,12,13]), or all (all)"),
+        click.option("-a", "--active", is_flag=True, default=None, help="Active Scan (accepted; the receive path is passive)"),
+        click.option("-n", "--num", "packets", type=int, default=None, help="Number of packets to scan for each channel"),
+        click.option("-t", "--timeout", type=float, default=None,
+                     help="Add a timeout restriction (in seconds) for each channel."),
+        click.option("--wideband", is_flag=True,
+                     help="--iq holds the whole band (BTLE: 80 Msps centred 2442 MHz, Zigbee: 32 Msps): every "
+                          "channel is received at once through the polyphase channelizer"),
+        click.option("--sharded", is_flag=True,
+                     help="wideband: cut the capture into overlapping segments, one GPU per rank "
+                          "(run under torch.distributed.run), records gathered on rank 0"),
+        click.option("--segment", type=int, default=1 << 24, help="wideband: input samples per segment"),
         click.option("-f", "--filename", default=None, help="dump file"),
         click.option("--iq", type=click.Path(exists=True), default=None, help="capture file"),
         click.option("--format", "fmt", type=click.Choice(sorted(FORMATS)), default="cf32",
@@ -77,9 +136,11 @@ def btle():
 @btle.command("scan")
 @_scan_options
 @click.option("--summary", is_flag=True, help="print the device table at the end (snout/util/btle.py:202-240)")
-def btle_scan(channels, packets, timeout, filename, iq, fmt, synthetic, seconds, summary):
-    chs = parse_channels(channels or DEFAULTS["btle"]["default"], "btle")
-    scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds, fmt),
+def btle_scan(channels, active, packets, timeout, wideband, sharded, segment, filename, iq, fmt, synthetic,
+              seconds, summary):
+    chs = parse_channels(channels, "btle")
+    packets, timeout = stop_conditions("btle", packets, timeout)
+    scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment),
                     timeout=timeout, packet_threshold=packets, filename=filename)
     scan.events.on("btle.packet-received",
                    lambda message: click.echo(message.raw.decode().rstrip("\n")))
@@ -98,9 +159,11 @@ def zigbee():
 @zigbee.command("scan")
 @_scan_options
 @click.option("--udp", is_flag=True, help="send RFtap datagrams to 127.0.0.1:52002 (scapy-radio)")
-def zigbee_scan(channels, packets, timeout, filename, iq, fmt, synthetic, seconds, udp):
-    chs = parse_channels(channels or DEFAULTS["zigbee"]["default"], "zigbee")
-    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds, fmt),
+def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, filename, iq, fmt, synthetic,
+                seconds, udp):
+    chs = parse_channels(channels, "zigbee")
+    packets, timeout = stop_conditions("zigbee", packets, timeout)
+    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment),
                       timeout=timeout, packet_threshold=packets, udp=udp)
     def show(message):
         from .formats import parse_mhr
@@ -133,6 +196,11 @@ def btle_rx(channel, gain, access, crcinit, iq, fmt):
     for line in scan.lines(channel):
         sys.stdout.write(line.decode())
     sys.stdout.flush()
+
+
+def btle_rx_main():
+    """Console entry `btle_rx`: the name the reference resolves on $PATH (snout/util/btle.py:53)."""
+    btle_rx.main(prog_name="btle_rx")
 
 
 if __name__ == "__main__":

@@ -103,6 +103,13 @@ __device__ __forceinline__ void lds_barrier()
 // waves per SIMD the register allocator must leave room for: 4 -> at most 128 VGPRs, three
 // 320-thread workgroups per CU (M = 40) / four 256-thread ones (M = 16); the fused 802.15.4
 // epilogue needs more registers and gets 3 (see PfbCtx::run)
+// FIR forms (A/B switches, tools/pfb_variants.sh): by default the window is read with one ds_read_b64
+// per sample and the MACs are v_pk_fma_f32 with the tap broadcast by op_sel; -DSNOUT_PFB_PLAIN_FIR
+// leaves both to the compiler (ds_read2_b64 pairs, every tap kept twice).
+#ifndef SNOUT_PFB_PLAIN_FIR
+#define SNOUT_PFB_PKFIR 1
+#define SNOUT_PFB_NOREAD2 1
+#endif
 #ifndef SNOUT_PFB_WPE
 #define SNOUT_PFB_WPE 4
 #endif
@@ -186,6 +193,11 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     float h[P];
 #pragma unroll
     for (int p = 0; p < P; p++) h[p] = proto[r + p * M];
+#ifdef SNOUT_PFB_PKFIR
+    v2f hp[P / 2];
+#pragma unroll
+    for (int p = 0; p < P / 2; p++) hp[p] = v2f{h[2 * p], h[2 * p + 1]};
+#endif
 
     static_assert((T * M2) % NT == 0 && T % 64 == 0, "pass 3a: whole rounds, wave-uniform n2");
     float tw3a[T * M2 / NT][2 * M1];               // W_M^{n2 k1} of this wave's n2 per round (scalar registers)
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int k = 0; k < NPRE; k++) reinterpret_cast<float4*>(xs)[OV4 + t + k * NT] = iq_pair_cvt<FMT>(pre[k]);
         lds_barrier();
+#if !defined(SNOUT_PFB_LATE_PREFETCH) && !defined(SNOUT_ABL_NOGLOBAL)
         if (tile + 1u < t_last) {
             const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
             if (in1 + NEW <= n) {                 // uniform: all NEW samples exist, no per-lane range tests
@@ -257,6 +270,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
                 for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in1 + 2ull * (uint64_t)(t + k * NT));
             }
         }
+#endif
 
         // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product
         {
@@ -287,6 +301,29 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int q = 0; q < 8 + P - 1; q++) w[q] = xs[base + q * M];
 #endif
+#if defined(SNOUT_ABL_NOFIRMATH)
+#pragma unroll
+            for (int i = 0; i < 8; i++) us[(e + 2 * (8 * grp + i)) * ROW + r] = make_float2(w[i].x + w[i + 15].x, w[i].y + w[i + 8].y);
+#elif defined(SNOUT_PFB_PKFIR)
+            // (re, im) of one output advance together in v_pk_fma_f32; the tap is broadcast to both halves
+            // by op_sel from a register PAIR holding two consecutive taps, so the 16 taps take 16
+            // registers (the compiler's own packing keeps every tap twice: 32)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                v2f acc;
+                {
+                    const v2f x0 = {w[i].x, w[i].y};
+                    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc) : "v"(hp[0]), "v"(x0));
+                }
+#pragma unroll
+                for (int p = 1; p < P; p++) {
+                    const v2f xv = {w[i + p].x, w[i + p].y};
+                    if (p & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(hp[p >> 1]), "v"(xv));
+                    else       asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(hp[p >> 1]), "v"(xv));
+                }
+                us[(e + 2 * (8 * grp + i)) * ROW + r] = make_float2(acc.x, acc.y);
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 float ar = 0.0f, ai = 0.0f;
@@ -297,12 +334,28 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
                 }
                 us[(e + 2 * (8 * grp + i)) * ROW + r] = make_float2(ar, ai);
             }
+#endif
         }
         if (t < OV4) keep = reinterpret_cast<const float4*>(xs)[NEW4 + t];   // next tile's overlap
         lds_barrier();
+#ifdef SNOUT_PFB_LATE_PREFETCH
+        // the next tile's samples are requested only now: they are not live across the FIR (its
+        // register peak), and the two FFT passes are time enough for them to land
+        if (tile + 1u < t_last) {
+            const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
+            if (in1 + NEW <= n) {                 // uniform: all NEW samples exist, no per-lane range tests
+#pragma unroll
+                for (int k = 0; k < NPRE; k++) pre[k] = iq_pair_raw<FMT>(x, in1 + 2ull * (uint64_t)(t + k * NT));
+            } else {
+#pragma unroll
+                for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in1 + 2ull * (uint64_t)(t + k * NT));
+            }
+        }
+#endif
 
         // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}; in place:
         //      slot M2 k1 + n2 of row m receives B[n2][k1]
+#ifndef SNOUT_ABL_NO3A
 #pragma unroll
         for (int rnd = 0; rnd < T * M2 / NT; rnd++) {
             // T is a multiple of 64, so n2 is the same for a whole wave: its twiddles W_M^{n2 k1} are
@@ -328,6 +381,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
                 }
             }
         }
+#endif
         lds_barrier();
 
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
@@ -346,7 +400,11 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             //      lanes come out of v_cmp as a wave mask; lanes (k2, k1 half g, a) pick the 2 x 8 bits of
             //      their channel and phase out of the masks and interleave them into the 16-bit quarter
             //      of the plane word.
+#ifdef SNOUT_ABL_NO3B
+            if (n == 0x123456789ull) {             // timing experiment: never true
+#else
             if (t < (T / 2) * M1) {
+#endif
                 const int mp = t & 31, k1 = t >> 5, a = mp & 3, b = mp >> 2;
                 const int mA = a + 8 * b;
                 cf YA[M2], YB[M2];

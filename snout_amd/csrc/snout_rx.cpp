@@ -1,5 +1,5 @@
 // snout_rx.cpp — the C ABI of libsnout_rx.so (include/snout_rx.h): handle management, argument
-// checking, the two-slot submit/collect pipeline (record D2H of segment i overlaps the kernels of
+// checking, the three-slot submit/collect pipeline (record D2H of segment i overlaps the kernels of
 // segment i+1 on a copy stream), H->D staging for the host-pointer entry point, profiling.
 #include "common.h"
 #include <stdarg.h>
@@ -458,10 +458,17 @@ int snout_rx_submit_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
         const int hi = (int)(h->hist_n % snout_rx::kHist);      // rotate the event pair of this slot
         std::swap(s.ev_k0, h->hist_k0[hi]);
         std::swap(s.ev_k1, h->hist_k1[hi]);
-        if (int rc = enqueue_segment(h, s, s.stream)) return rc;
-        if (int rc = enqueue_copy(h, s, h->spec)) return rc;
+        int rc = enqueue_segment(h, s, s.stream);
+        if (!rc) rc = enqueue_copy(h, s, h->spec);
         std::swap(s.ev_k0, h->hist_k0[hi]);                     // pool[hi] now holds this segment's pair
         std::swap(s.ev_k1, h->hist_k1[hi]);
+        if (rc) {
+            // nothing was submitted: the work-set rotation must stay in phase with the slot ring, and
+            // whatever was enqueued before the failure has to be off the work set before it is reused
+            h->n_submitted--;
+            (void)hipDeviceSynchronize();
+            return rc;
+        }
         s.hist_idx = hi;
         h->hist_n++;
         s.timed = true;
@@ -514,7 +521,7 @@ int snout_rx_last_records_dev(snout_rx* h, const snout_pkt** recs_dev, uint64_t*
 
 int snout_rx_collect(snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out)
 {
-    if (!out && cap) return SNOUT_EINVAL;
+    if (!n_out || (!out && cap)) return SNOUT_EINVAL;
     const snout_pkt* recs = nullptr;
     uint64_t np = 0;
     if (int rc = snout_rx_collect_view(h, &recs, &np)) return rc;
@@ -649,6 +656,7 @@ int snout_rx_soft(snout_rx* h, uint32_t stage, uint32_t channel_slot, float* out
         *n_out = nf;
         return nf > cap ? SNOUT_EOVERFLOW : SNOUT_OK;
     }
+    if (!h->last) { set_last_error("no processed segment: nothing to tap"); return SNOUT_EINVAL; }
     if (stage == SNOUT_STAGE_BTLE_BITS && h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = btle_of(h, *h->last);
         if (channel_slot >= b.n_slots || h->last_nch < 5) return SNOUT_EINVAL;

@@ -63,6 +63,75 @@ class ArraySource(IqSource):
         return self.arrays[channel]
 
 
+class WidebandSource(IqSource):
+    """One capture of the WHOLE band (BTLE: 80 Msps centred on 2442 MHz; 802.15.4: the 32 Msps
+    synthetic raster, SURVEY §8d cfg #3 / #4): every channel is received in one pass through the
+    polyphase channelizer -- what the reference does by hopping (snout/core/radio.py:415).  The
+    capture is cut into overlapping segments that are pumped through the GPU with submit / collect
+    (``ShardedScan``); with ``sharded=True`` under ``torch.distributed.run`` segment i goes to rank
+    i mod N and rank 0 gets every record (cfg #5).  ``records(channel)`` then serves
+    the scan loop channel by channel, in capture order."""
+
+    def __init__(self, capture, proto: int, sample_format: int = 0, segment: int = 1 << 24,
+                 sharded: bool = False, device: int = -1):
+        self.capture = capture            # path of a capture file, or an array (complex64 / int pairs)
+        self.proto = int(proto)
+        self.sample_format = int(sample_format)
+        self.segment = int(segment)
+        self.sharded = bool(sharded)
+        self.device = device
+        self.rank = 0
+        self._rec = None
+
+    def _array(self) -> np.ndarray:
+        if isinstance(self.capture, np.ndarray):
+            return self.capture
+        return FileSource(self.capture, self.sample_format).read(0)
+
+    def _scan(self) -> np.ndarray:
+        import torch
+        import torch.distributed as tdist
+        from .sharded import ShardedScan
+        x = self._array()
+        n_total = len(x)
+        group_made = False
+        if self.sharded and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not tdist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            lr = int(os.environ.get("LOCAL_RANK", "0"))
+            backend = os.environ.get("SNOUT_BENCH_BACKEND", "nccl")
+            torch.cuda.set_device(lr % max(1, torch.cuda.device_count()))
+            tdist.init_process_group(backend)
+            group_made = True
+        self.rank = tdist.get_rank() if tdist.is_initialized() else 0
+        dev = torch.device("cuda", torch.cuda.current_device())
+        M = 40 if self.proto == _ffi.PROTO_BTLE else 16
+        sc = ShardedScan(self.proto, n_channels=M, seg_len=self.segment, device=self.device,
+                         sample_format=self.sample_format)
+
+        def source(a, b):
+            chunk = np.ascontiguousarray(x[a:b])
+            if chunk.dtype == np.complex64:
+                chunk = chunk.view(np.float32)
+            return torch.from_numpy(chunk.reshape(-1)).to(dev, non_blocking=False)
+        try:
+            rec = sc.run(n_total, source, gather_device=dev)
+        finally:
+            sc.close()
+            if group_made:
+                tdist.barrier()
+                tdist.destroy_process_group()
+        return rec if rec is not None else np.zeros(0, dtype=_ffi.PKT_DTYPE)
+
+    def records(self, channel: int) -> np.ndarray:
+        if self._rec is None:
+            self._rec = self._scan()           # sorted by (proto, channel, sample_index), duplicates dropped
+        r = self._rec
+        return r[r["channel"] == channel]
+
+    def read(self, channel: int) -> np.ndarray:
+        raise TypeError("a wideband capture is not read per channel: use records(channel)")
+
+
 class _Events:
     """Minimal event bus (reference: snout/core/__init__.py:18-58)."""
 
@@ -102,6 +171,12 @@ class BtleScan:
     def lines(self, channel: int):
         """Yield btle_rx-grammar lines (bytes) for every PDU found on `channel`, CRC0 and CRC1
         alike, in capture order — what the reference reads from the child's stdout."""
+        if hasattr(self.source, "records"):          # wideband capture: every channel was received at once
+            for p in self.source.records(channel):
+                self._elapsed = int(p["sample_index"]) / BTLE_FS
+                yield btle_format_line(p, BTLE_FS, self.t0_epoch, self._pkt_no, self.access_addr)
+                self._pkt_no += 1
+            return
         x = self.source.read(channel)
         with SnoutRx(proto=_ffi.PROTO_BTLE, channel=channel, access_addr=self.access_addr,
                      crc_init=self.crc_init, device=self.device,
@@ -177,6 +252,11 @@ class ZigbeeScan:
         self._elapsed = 0.0
 
     def frames(self, channel: int):
+        if hasattr(self.source, "records"):          # wideband capture: every channel was received at once
+            for p in self.source.records(channel):
+                self._elapsed = int(p["sample_index"]) / ZIGBEE_FS
+                yield p
+            return
         x = self.source.read(channel)
         with SnoutRx(proto=_ffi.PROTO_ZIGBEE, channel=channel, device=self.device,
                      sample_format=getattr(self.source, "sample_format", 0)) as rx:

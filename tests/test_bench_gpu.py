@@ -1,7 +1,8 @@
-"""GPU: bench.py's contract — one JSON line with the required keys at N = 1, and the multi-rank
-orchestration (rank env, per-step record gather, barrier, max over ranks) with two ranks.  The box
-has one GPU, so the two ranks share it and talk over gloo (SNOUT_BENCH_BACKEND): a check of the
-code path, not a measurement; the nccl pieces are covered at world size 1 in test_btle_gpu.py."""
+"""GPU: bench.py's contract — one JSON line with the required keys at N = 1 (headline cfg #3 with
+`roofline`, `cpu_baseline` and `other_workloads`), and the multi-rank orchestration of cfg #5 (rank
+env, segments dealt round-robin, per-step record gather + de-duplication on rank 0, barrier, max over
+ranks) with two ranks.  The box has one GPU, so the two ranks share it and talk over gloo
+(SNOUT_BENCH_BACKEND): a check of the code path, not a measurement."""
 import json
 import os
 import socket
@@ -14,6 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline"}
+METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 
 
 def _last_json(out: bytes) -> dict:
@@ -22,48 +24,87 @@ def _last_json(out: bytes) -> dict:
     return json.loads(lines[0])
 
 
-def test_single_gpu_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
-                        "--samples", "6e7", "--cpu-samples", "2e7"], capture_output=True, timeout=600)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    d = _last_json(r.stdout)
-    assert KEYS <= set(d) and "cpu_baseline" in d
+def _bench(*args, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True,
+                       timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return _last_json(r.stdout)
+
+
+def test_headline_is_the_wideband_metric():
+    d = _bench("--steps", "3", "--warmup", "1", "--samples", "4e7", "--cpu-samples", "4e6", "--no-others")
+    assert KEYS <= set(d) and d["metric"] == METRIC                       # BASELINE.json's string, unchanged
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["config"]["workload"].startswith("cfg3")
+    c = d["config"]
+    assert c["decoded_crc_ok_per_gpu"] >= c["expected_crc_ok_per_gpu"] > 0
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["kernel"] == "pfb_channelize<40>" and rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
-    assert rf["traffic"] is None                       # the PMC figure is for the 1e9-sample workload only
+    assert abs(rf["algorithmic_bytes"] - (8 * 4e7 + 160 * c["packets_per_gpu"])) < 1
+    assert 2000 < rf["measured_read_GBps"] < 8000 and rf["frac_of_measured_read"] > rf["frac"]
+    assert 0 < rf["fp32"]["frac"] < 1 and rf["fp32"]["peak_TFLOPs"] == 157.3 and 181 < rf["fp32"]["flop_per_sample"] < 182
+    assert rf["traffic"] is None                                           # the PMC figure is for the full-size workload
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and d["value"] > 20 * cb["value"]
+    assert cb["all_cores"]["cores"] == cb["nproc"] >= 1 and cb["all_cores"]["value"] > 0 and cb["cpu_model"]
 
 
-def test_two_ranks_share_the_gpu_over_gloo():
+def test_default_run_carries_every_workload():
+    d = _bench("--steps", "3", "--warmup", "1", timeout=1500)
+    assert d["config"]["samples_per_gpu"] == 800000000 and "cpu_baseline" in d
+    ow = d["other_workloads"]
+    assert set(ow) == {"cfg2", "cfg4", "zigbee1", "cfg5"}
+    for name, kern in (("cfg2", "btle_demod_corr"), ("cfg4", "pfb_channelize<16>"), ("zigbee1", "zb_discrim..zb_walk")):
+        w = ow[name]
+        assert w["kernel"] == kern and w["value"] > 0 and w["kernel_ms"] > 0 and 0 < w["frac"] < 1
+        assert w["decoded_crc_ok_per_gpu"] >= w["expected_crc_ok_per_gpu"] > 0
+    assert ow["cfg5"]["segments_per_gpu"] == 48 + 20 and ow["cfg5"]["decoded_crc_ok"] >= ow["cfg5"]["expected_crc_ok"] > 0
+
+
+def test_two_ranks_run_cfg5_over_gloo():
+    """`--gpus N` = BASELINE.json configs[4]: both wideband scans, segments round-robin over the ranks,
+    records gathered and de-duplicated on rank 0 inside the timed region."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SNOUT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--seconds", "1"], capture_output=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" not in d      # the CPU baseline is timed at N = 1 only
+    assert d["metric"] == METRIC and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    c = d["config"]
+    assert c["workload"].startswith("cfg5") and c["samples_per_gpu"] == 80000000 + 32000000
+    assert c["decoded_crc_ok"] >= c["expected_crc_ok"] > 0 and "gloo" in c["sharding"]
+    # one rank alone on the same virtual capture length finds the same frames (the duplicates of the
+    # overlaps between ranks are dropped on rank 0): per GPU the two-rank run decodes as many
+    one = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1")
+    assert abs(c["decoded_crc_ok"] - 2 * one["config"]["decoded_crc_ok"]) <= 0.02 * c["decoded_crc_ok"]
+
+
+def test_two_ranks_single_workload_over_gloo():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SNOUT_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                        "--samples", "6e7"], capture_output=True, timeout=900, env=env)
+                        "--workload", "cfg2", "--samples", "6e7"], capture_output=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = _last_json(r.stdout)
-    assert KEYS <= set(d) and "cpu_baseline" not in d      # the CPU baseline is timed at N = 1 only
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["samples_per_gpu"] == 60000000
+    assert d["n_gpus"] == 2 and d["config"]["samples_per_gpu"] == 60000000 and d["value"] > 0
 
 
 @pytest.mark.parametrize("workload,samples,cpu,name", [
-    ("cfg3", 40 * (1 << 18), 40 * (1 << 16), "pfb_channelize<40>"),
+    ("cfg2", 6e7, 2e7, "btle_demod_corr"),
     ("cfg4", 16 * (1 << 19), 16 * (1 << 17), "pfb_channelize<16>"),
     ("zigbee1", 1 << 23, 1 << 21, "zb_discrim..zb_walk"),
 ])
 def test_other_workloads_keep_the_contract(workload, samples, cpu, name):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3",
-                        "--warmup", "1", "--samples", str(samples), "--cpu-samples", str(cpu)],
-                       capture_output=True, timeout=900)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    d = _last_json(r.stdout)
+    d = _bench("--workload", workload, "--steps", "3", "--warmup", "1", "--samples", str(samples),
+               "--cpu-samples", str(cpu))
     assert KEYS <= set(d) and d["config"]["workload"].startswith(workload.replace("zigbee1", "single-channel 802"))
     assert d["roofline"]["kernel"] == name and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["traffic"] is None
     c = d["config"]
@@ -72,10 +113,8 @@ def test_other_workloads_keep_the_contract(workload, samples, cpu, name):
 
 
 def test_integer_input_format_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--format", "sc8", "--steps", "3",
-                        "--warmup", "1", "--samples", "6e7", "--cpu-samples", "2e7"], capture_output=True, timeout=600)
-    assert r.returncode == 0, r.stderr.decode()[-2000:]
-    d = _last_json(r.stdout)
+    d = _bench("--workload", "cfg2", "--format", "sc8", "--steps", "3", "--warmup", "1", "--samples", "6e7",
+               "--cpu-samples", "2e7")
     assert KEYS <= set(d) and d["dtype"] == "i8->i32" and "sc8" in d["config"]["workload"]
     # 2 B per sample: the algorithmic bytes of the roofline follow the format
     assert abs(d["roofline"]["algorithmic_bytes"] - (2 * 6e7 + 160 * d["config"]["packets_per_gpu"])) < 1

@@ -6,14 +6,52 @@ from snout_amd import cli, formats
 
 
 def test_parse_channels_like_reference():
+    """Grammar of ChannelsOption + get_channels (snout/util/iot_click.py:46-92, snout/cli.py:139-183)."""
     assert cli.parse_channels("37", "btle") == [37]
-    assert cli.parse_channels("37,38,39", "btle") == [37, 38, 39]
+    assert cli.parse_channels("37,38,39", "btle") == [37, 38, 39]          # literal tuple -> as given
+    assert cli.parse_channels("[11,12,13]", "zigbee") == [11, 12, 13]
+    assert cli.parse_channels("[15]", "zigbee") == [15, 15]                # upstream doubles a one-element list
     assert cli.parse_channels("11:14", "zigbee") == [11, 12, 13, 14]
-    assert cli.parse_channels("", "zigbee") == [11]
+    assert cli.parse_channels("11-14", "zigbee") == [11, 12, 13, 14]
+    assert cli.parse_channels("all", "zigbee") == list(range(11, 27))
+    assert cli.parse_channels("ALL", "btle") == list(range(0, 40))
+    assert cli.parse_channels("", "zigbee") == [11] and cli.parse_channels(None, "btle") == [37]
+    for bad, proto in (("40", "btle"), ("10", "zigbee"), ("11:27", "zigbee"), ("x", "btle"), ("{1:2}", "btle")):
+        with pytest.raises(Exception):
+            cli.parse_channels(bad, proto)
+
+
+def test_stop_conditions_defaults(monkeypatch):
+    """snout/cli.py:246-250: with neither -n nor -t the reference asks for both; without a terminal the
+    prompts' defaults apply (no packet threshold, the protocol's timeout of snout/util/__init__.py:4-9)."""
+    import io
+    monkeypatch.setattr("sys.stdin", io.StringIO(""))
+    assert cli.stop_conditions("btle", None, None) == (None, 10.0)
+    assert cli.stop_conditions("zigbee", 5, None) == (5, None)
+    assert cli.stop_conditions("zigbee", None, 2.5) == (None, 2.5)
+    assert cli.stop_conditions("btle", 0, None) == (None, None)            # --num 0: unlimited, as upstream
     with pytest.raises(Exception):
-        cli.parse_channels("40", "btle")
-    with pytest.raises(Exception):
-        cli.parse_channels("10", "zigbee")
+        cli.stop_conditions("btle", -1, None)
+
+
+def test_console_entries_and_option_names():
+    """`snout {btle,zigbee} scan` with the reference's option names (-c/--channels, -a/--active, -n/--num,
+    -t/--timeout: snout/cli.py:220-236), the in-tree entry scripts and setup.py's console_scripts."""
+    import os
+    import subprocess
+    import sys
+    from click.testing import CliRunner
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for proto in ("btle", "zigbee"):
+        out = CliRunner().invoke(cli.main, [proto, "scan", "--help"]).output
+        for opt in ("-c, --channels", "-a, --active", "-n, --num", "-t, --timeout", "--wideband", "--sharded"):
+            assert opt in out, (proto, opt)
+    r = subprocess.run([sys.executable, os.path.join(root, "bin", "snout"), "--help"], capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"btle" in r.stdout and b"zigbee" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bin", "btle_rx"), "--help"], capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"-c" in r.stdout and b"-k" in r.stdout
+    setup = open(os.path.join(root, "setup.py")).read()
+    assert "snout = snout_amd.cli:main" in setup and "btle_rx = snout_amd.cli:btle_rx_main" in setup
 
 
 def test_pcap_roundtrip(tmp_path):

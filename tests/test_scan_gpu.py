@@ -1,0 +1,97 @@
+"""GPU: the scan surface around the receive path — the UDP hand-over to scapy-radio
+(Zigbee_rx/top_block.py:71 `socket_pdu("UDP_CLIENT", '127.0.0.1', '52002', ...)`, consumer
+snout/core/radio.py:232-237), the wideband / sharded modes of `snout {btle,zigbee} scan`."""
+import json
+import os
+import socket
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from snout_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_udp_52002_receives_what_the_flowgraph_would_send():
+    """Bind the port scapy-radio's GnuradioSocket listens on, run ZigbeeScan(udp=True) and check every
+    datagram: RFtap header (magic, len32 = 4, flags 0x81, DLT 195, qual = lqi / 255) + MPDU incl. FCS."""
+    from snout_amd.scan import ArraySource, ZigbeeScan
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    try:
+        rx.bind(("127.0.0.1", 52002))
+    except OSError:
+        pytest.skip("UDP 52002 is taken on this box")
+    rx.settimeout(5.0)
+    try:
+        x, truth = synth.zigbee_capture(1 << 19, channel=15, seed=31, mean_gap=15000.0)
+        scan = ZigbeeScan(channels=[15], source=ArraySource({15: x}), timeout=None, udp=True)
+        msgs = scan.run()
+        got = []
+        for _ in msgs:
+            got.append(rx.recvfrom(4096)[0])
+    finally:
+        rx.close()
+    assert len(got) == len(msgs) >= len(truth) > 5
+    sent = {t.payload for t in truth}
+    for d, m in zip(got, msgs):
+        assert d == m.datagram and d[:4] == b"RFta"
+        len32, flags, dlt = struct.unpack("<HHI", d[4:12])
+        assert (len32, flags, dlt) == (4, 0x0081, 195)
+        assert abs(struct.unpack("<f", d[12:16])[0] - m.lqi / 255.0) < 1e-6
+        assert d[16:] == m.mpdu
+    assert sum(1 for m in msgs if m.mpdu in sent) == len(truth)
+
+
+def test_wideband_source_equals_the_oracle(oracle):
+    """BtleScan over a whole-band capture (WidebandSource -> ShardedScan -> channelizer handle, several
+    overlapping segments) reports what the oracle's wideband receiver finds in one piece."""
+    from snout_amd.scan import BtleScan, WidebandSource
+    x, truth = synth.wideband_capture(0, 40 * 60000, seed=9, mean_gap=9000.0)
+    src = WidebandSource(x, 0, segment=40 * 20000)
+    chans = sorted({t.channel for t in truth})
+    scan = BtleScan(channels=chans, source=src, timeout=None, t0_epoch=0.0)
+    lines = []
+    scan.events.on("btle.packet-received", lambda message: lines.append(message))
+    msgs = scan.run()
+    want = oracle.wideband_segment(x, proto=0)
+    want_ok = want[want["crc_ok"] == 1]
+    assert len(msgs) == len(want_ok) >= 0.9 * len(truth)
+    assert sorted(int(m.channel) for m in msgs) == sorted(int(c) for c in want_ok["channel"])
+    sent = {t.payload[2:8][::-1].hex() for t in truth}
+    assert {m.sender for m in msgs} <= sent
+
+
+def test_cli_wideband_scan_all_channels():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "snout"), "btle", "scan", "--wideband", "--synthetic",
+                        "--seconds", "0.02", "-c", "all", "-t", "1"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    from snout_amd.message import BtleMessage
+    msgs = [m for m in (BtleMessage.fromraw(ln) for ln in r.stdout.splitlines(keepends=True)) if m]
+    assert len(msgs) >= 20 and len({m.channel for m in msgs}) >= 10
+    assert all(m.access_address == "8e89bed6" for m in msgs)
+
+
+def test_cli_sharded_two_ranks_over_gloo(tmp_path):
+    """`--sharded` under torch.distributed.run: segments dealt round-robin, records gathered on rank 0,
+    the same frames as one rank finds."""
+    x, truth = synth.wideband_capture(1, 16 * 150000, seed=4, bins=range(0, 16, 2), max_len=60)
+    path = str(tmp_path / "zb_wide.cf32")
+    x.tofile(path)
+    cmd = [os.path.join(ROOT, "bin", "snout"), "zigbee", "scan", "--sharded", "--iq", path, "--segment", str(16 * 50000),
+           "-c", "all", "-t", "5"]
+    one = subprocess.run([sys.executable] + cmd, capture_output=True, timeout=600)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SNOUT_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + cmd,
+                         capture_output=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    f1 = sorted(ln.split()[-1] for ln in one.stdout.decode().splitlines() if " Ch" in ln)
+    f2 = sorted(ln.split()[-1] for ln in two.stdout.decode().splitlines() if " Ch" in ln)
+    assert len(f1) >= 0.8 * len(truth) and f1 == f2

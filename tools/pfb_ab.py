@@ -50,8 +50,14 @@ if __name__ == "__main__":
     if "--samples" in args:
         i = args.index("--samples"); ns = float(args[i + 1]); del args[i:i + 2]
     for name in args:
+        blocks = None
+        if "@" in name:                                     # name@1024: persistent grid of the channelizer
+            name, blocks = name.split("@")
         lib = os.path.join(ROOT, "build", "variants", f"libsnout_rx_{name}.so")
         env = dict(os.environ, SNOUT_RX_LIB=lib)
+        if blocks:
+            env["SNOUT_PFB_BLOCKS"] = blocks
+            name = f"{name}@{blocks}"
         r = subprocess.run([sys.executable, __file__, "--child", "--proto", str(proto), "--samples", str(ns)],
                            env=env, capture_output=True, text=True, timeout=900)
         out = (r.stdout.strip().splitlines() or ["(no output)"])[-1]
