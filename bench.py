@@ -111,10 +111,11 @@ def expected_ok(workload: str, truth, tile_len: int, n_samples: int) -> int:
     if workload == "cfg2":
         rem = n_samples - full * tile_len
         return full * len(truth) + sum(1 for p in truth if p.sample_index + 1600 < rem)
-    # wideband truth indices are at the channel rate and 802.15.4 frames are up to 4256 samples
-    # long: count whole tiles only, and allow for the frames a repetition cuts short (cfg4: the
-    # synthetic 2 MHz raster makes adjacent 802.15.4 channels overlap spectrally)
-    return int((0.4 if workload == "cfg4" else 0.9) * full * len(truth))
+    # wideband truth indices are at the channel rate: count whole tiles only.  cfg4: the synthetic
+    # 2 MHz raster makes adjacent 802.15.4 channels overlap spectrally; their traffic is slotted so
+    # that neighbours never transmit together, but a neighbour's leakage still drags the receiver's
+    # DC estimate before some frames: ~93 % decode on the oracle and on the GPU alike
+    return int((0.8 if workload == "cfg4" else 0.9) * full * len(truth))
 
 
 def quantise(x, fmt: int):
@@ -412,7 +413,7 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
         rb, rz = results[-1]
         ok_b, ok_z = int(rb["crc_ok"].sum()), int(rz["crc_ok"].sum())
         exp_b = int(0.9 * (nb // tb.size) * len(truth_b))
-        exp_z = int(0.4 * (nz // tz.size) * len(truth_z))
+        exp_z = int(0.8 * (nz // tz.size) * len(truth_z))
         assert ok_b >= exp_b and ok_z >= exp_z, (ok_b, exp_b, ok_z, exp_z)
         key = (rb["channel"].astype(np.uint64) << np.uint64(48)) | rb["sample_index"]
         assert np.all(key[1:] > key[:-1]), "BTLE records on rank 0 are not sorted / de-duplicated"

@@ -238,7 +238,20 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
  * chip.  Sinks that start at different chips fall into step as soon as both are searching with a
  * full register; until then they may first match different symbols of one preamble, but they find
  * the start-of-frame delimiter at the same chip, so a frame is reported by the lane that owns the
- * chip completing its SFD (its sample_index is where THAT sink first matched the preamble).
+ * chip completing its SFD.
+ *
+ * Resolve (what makes the lanes' frames those of ONE sequential sink).  The sequential sink is busy
+ * from the chip that first matched a preamble symbol (its trigger) to the chip that completes the
+ * frame, and searches again only from the next chip: it cannot report a frame that begins inside
+ * another one.  A lane's sink that starts inside a frame can (it false-syncs on payload symbols).
+ * So the candidate frames of all lanes, in the order of their SFD chips, are passed through the
+ * sequential rule: a frame is kept iff its trigger chip lies after the last chip of the frame kept
+ * before it.
+ *
+ * sample_index.  Which preamble symbol a sink matches first depends on where it started, the SFD
+ * chip does not: the record's sample_index is the window start of the chip 319 chips before the
+ * one that completes the SFD (= the first chip of a regular 8-symbol preamble + 2-symbol SFD; chip
+ * 0 if the stream is shorter), the same for every sink that finds the frame.
  * With core >= n (one lane) this is the reference's sequential receiver.
  */
 #define ORACLE_ZB_SINK_WARM 512u
@@ -422,6 +435,8 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         for (uint64_t j = (nc >= 64 ? nc - 64 : 0); j < nc; j++) prev_hist = (prev_hist << 1) | lb[j];
     }
     o[n_lanes] = total;
+    uint64_t busy_end = 0;          /* last chip of the frame kept last (sequential rule) */
+    int have_kept = 0;
     for (uint64_t l = 0; l < n_lanes; l++) {
         lane_t s;
         memset(&s, 0, sizeof(s));
@@ -433,10 +448,14 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
              * match different preamble symbols, but they all find the SFD at the same chip */
             if (done && (s.sync < o[l] || s.sync >= o[l + 1])) { enter_search(&s); continue; }
             if (done) {
+                /* resolve: the sequential sink is busy until the end of the frame it kept last */
+                if (have_kept && s.trigger <= busy_end) { enter_search(&s); continue; }
+                have_kept = 1;
+                busy_end = q;
                 if (*n_out < cap) {
                     snout_pkt* p = &out[*n_out];
                     memset(p, 0, sizeof(*p));
-                    p->sample_index = first_index + spos[s.trigger];
+                    p->sample_index = first_index + spos[s.sync >= 319u ? s.sync - 319u : 0u];
                     p->proto = 1;
                     p->channel = (uint16_t)channel;
                     p->len = (uint16_t)s.packetlen_cnt;

@@ -853,9 +853,12 @@ __global__ __launch_bounds__(256) void zb_walk(
                 if (n_pk < K) {
                     // window start of the trigger chip: chip j of the lane gt that owns it (this lane
                     // or one before it), found in that lane's tile records
+                    // sample_index: the chip 319 chips before the one that completed the SFD (the first chip
+                    // of a regular preamble + SFD), the same for every sink that finds this frame
+                    const uint32_t rq = sync_q >= 319u ? sync_q - 319u : 0u;
                     uint32_t gt = g;
-                    while (s.trigger < offs[gt]) gt--;      // same channel: the sink started inside it
-                    const uint32_t j = first_owned[gt] + (s.trigger - offs[gt]);
+                    while (rq < offs[gt]) gt--;             // same channel: chip 0 belongs to its lane 0
+                    const uint32_t j = first_owned[gt] + (rq - offs[gt]);
                     const uint32_t w = gt >> 6, row = gt & 63u;
                     uint32_t lo = 0, hi2 = nt;          // last tile with cstart <= j and nc > 0 reaching j
                     while (hi2 - lo > 1u) {
@@ -894,6 +897,10 @@ __global__ __launch_bounds__(256) void zb_walk(
                     // FCS: CRC-16 over all but the last two bytes == those two bytes (LE)
                     const uint32_t rx = s.b_prev | (s.b_last << 8);
                     p->crc_ok = (uint8_t)(len >= 3u && s.c2 == rx);
+                    // for zb_resolve (cleared by zb_emit): the chips this sink was busy with the frame
+                    uint32_t* span = reinterpret_cast<uint32_t*>(&p->bytes[128]);
+                    span[0] = s.trigger;
+                    span[1] = q - 1u;
                 }
                 n_pk++;
             }
@@ -903,9 +910,74 @@ __global__ __launch_bounds__(256) void zb_walk(
     if (exists) lane_cnt[g] = n_pk;
 }
 
-// Ordered compaction of per-lane records: lane g holds min(lane_cnt[g], K) records.
+// The sequential rule over the candidate frames of all lanes (see the oracle, "Resolve"): in the
+// order of their SFD chips (= lane order, then time), a frame is kept iff its trigger chip lies after
+// the last chip of the frame kept before it -- the one sequential sink is busy until then, only a
+// lane sink that started inside that frame can have found something there.  One thread per lane
+// decides its own records: a frame ends at most kMaxBusy chips after its SFD chip, so only the
+// records of the last few lanes can reach a given trigger; walking back, the thread gathers the
+// records that can (transitively) matter -- those whose last chip is not before the smallest
+// trigger gathered so far -- and replays the rule over them.  Marks dropped records (pdu_type = 1)
+// and writes the lane's kept count.
+constexpr uint32_t kMaxBusy = (2u + 2u * 128u) * 32u;       // PHR + PSDU symbols after the SFD chip
+constexpr int kResolveSet = 48;
+
+__global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage, const uint32_t* __restrict__ lane_cnt,
+                                                  uint32_t K, uint32_t lanes_per_slot, uint32_t total_lanes,
+                                                  const uint32_t* __restrict__ offs, uint32_t* __restrict__ lane_kept)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total_lanes) return;
+    const uint32_t raw = lane_cnt[g];
+    if (raw > K) { lane_kept[g] = raw; return; }          // overflow: the segment is run again with more slots
+    const uint32_t g_first = g - g % lanes_per_slot;        // first lane of this channel
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < raw; i++) {
+        uint32_t trig[kResolveSet], endc[kResolveSet];
+        int ns = 0;
+        const uint32_t* me = reinterpret_cast<const uint32_t*>(&stage[(size_t)g * K + i].bytes[128]);
+        trig[0] = me[0]; endc[0] = me[1]; ns = 1;
+        uint32_t tmin = me[0];
+        // walk back over the records before (g, i)
+        uint32_t gl = g;
+        int idx = (int)i - 1;
+        for (;;) {
+            if (idx < 0) {
+                if (gl == g_first) break;
+                gl--;
+                // every frame of the lanes up to gl has its SFD chip before offs[gl + 1]
+                if ((uint64_t)offs[gl + 1u] + kMaxBusy < (uint64_t)tmin) break;
+                const uint32_t c = lane_cnt[gl];
+                idx = (int)(c < K ? c : K) - 1;
+                continue;
+            }
+            const uint32_t* r = reinterpret_cast<const uint32_t*>(&stage[(size_t)gl * K + (uint32_t)idx].bytes[128]);
+            const uint32_t rt = r[0], re = r[1];
+            if (re >= tmin && ns < kResolveSet) {           // it reaches something gathered: it matters
+                trig[ns] = rt; endc[ns] = re; ns++;
+                tmin = rt < tmin ? rt : tmin;
+            }
+            idx--;
+        }
+        // replay, oldest first; entry 0 is this record
+        bool have = false, keep_me = true;
+        uint32_t busy = 0;
+        for (int k = ns - 1; k >= 0; k--) {
+            const bool drop = have && trig[k] <= busy;
+            if (!drop) { have = true; busy = endc[k]; }
+            if (k == 0) keep_me = !drop;
+        }
+        stage[(size_t)g * K + i].pdu_type = keep_me ? 0 : 1;
+        kept += keep_me ? 1u : 0u;
+    }
+    lane_kept[g] = kept;
+}
+
+// Ordered compaction of per-lane records: lane g holds min(lane_cnt[g], K) records, of which
+// lane_kept[g] survived zb_resolve (pdu_type == 0).
 __global__ __launch_bounds__(256) void zb_emit(const snout_pkt* __restrict__ stage,
-                                               const uint32_t* __restrict__ lane_cnt, uint32_t K,
+                                               const uint32_t* __restrict__ lane_cnt,
+                                               const uint32_t* __restrict__ lane_kept, uint32_t K,
                                                uint32_t total_lanes,
                                                const uint32_t* __restrict__ tile_sums,
                                                const uint32_t* __restrict__ tile_over,
@@ -937,8 +1009,9 @@ __global__ __launch_bounds__(256) void zb_emit(const snout_pkt* __restrict__ sta
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t c = (g0 + k < total_lanes) ? lane_cnt[g0 + k] : 0u;
+        uint32_t kp = (g0 + k < total_lanes) ? lane_kept[g0 + k] : 0u;
         cnt[k] = c < K ? c : K;
-        s += cnt[k];
+        s += kp < K ? kp : K;
     }
     // exclusive scan of s over the block
     uint32_t inc = s;
@@ -956,11 +1029,16 @@ __global__ __launch_bounds__(256) void zb_emit(const snout_pkt* __restrict__ sta
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         for (uint32_t i = 0; i < cnt[k]; i++) {
+            const snout_pkt* rec = &stage[(size_t)(g0 + k) * K + i];
+            if (rec->pdu_type != 0) continue;               // dropped by zb_resolve
             if (off < out_cap) {
-                const uint4* src = reinterpret_cast<const uint4*>(&stage[(size_t)(g0 + k) * K + i]);
+                const uint4* src = reinterpret_cast<const uint4*>(rec);
                 uint4* dst = reinterpret_cast<uint4*>(&out[off]);
 #pragma unroll
-                for (int q = 0; q < 10; q++) dst[q] = src[q];
+                for (int q = 0; q < 9; q++) dst[q] = src[q];
+                uint4 tail = src[9];
+                tail.z = 0u; tail.w = 0u;                   // bytes[128..135]: the resolve stash
+                dst[9] = tail;
             }
             off++;
         }
@@ -1040,7 +1118,7 @@ int ZbCtx::reserve(uint64_t n)
     if (int rc = d_lane_u32.ensure(((uint64_t)total_lanes * 3u + (uint64_t)tiles_per_slot * n_slots + n_slots) * 4u)) return rc;
     if (int rc = d_stream.ensure(stream_words * n_slots * 8u * 2u)) return rc;     // chips | match masks
     if (int rc = d_stage.ensure((uint64_t)total_lanes * pkts_per_lane * sizeof(snout_pkt))) return rc;
-    if (int rc = d_lane_cnt.ensure(((uint64_t)total_lanes + 1024u) * 4u)) return rc;
+    if (int rc = d_lane_cnt.ensure(2u * ((uint64_t)total_lanes + 1024u) * 4u)) return rc;     // raw counts, kept counts
     max_out = total_lanes * pkts_per_lane;
     if (int rc = d_soft.ensure(((uint64_t)kSoftCap * 2u + 16u) * 4u)) return rc;
     nsb = (n + 63u) / 64u;
@@ -1192,10 +1270,13 @@ int ZbCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, Result
     if (int rc = launch_sinks(first_index, st)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
-    launch_tile_reduce(d_lane_cnt.as<uint32_t>(), nullptr, total_lanes, total_lanes, pkts_per_lane,
+    uint32_t* lane_kept = d_lane_cnt.as<uint32_t>() + total_lanes + 1024u;
+    hipLaunchKernelGGL(zb_resolve, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_stage.as<snout_pkt>(),
+                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, lanes_per_slot, total_lanes, d_lane_u32.as<uint32_t>() + 2u * (uint64_t)total_lanes, lane_kept);
+    launch_tile_reduce(lane_kept, nullptr, total_lanes, total_lanes, pkts_per_lane,
                        sums, over, n_tiles, st);
     hipLaunchKernelGGL(zb_emit, dim3(n_tiles), dim3(256), 0, st, d_stage.as<snout_pkt>(),
-                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, total_lanes, sums, over, n_tiles, tot,
+                       d_lane_cnt.as<uint32_t>(), lane_kept, pkts_per_lane, total_lanes, sums, over, n_tiles, tot,
                        s.d_out.as<snout_pkt>(), max_out);
     SNOUT_HIP(hipGetLastError());
     return 0;

@@ -26,6 +26,7 @@ ZIGBEE_FS = 4e6
 SEGMENT = 1 << 24           # samples per processing segment
 BTLE_OVERLAP = 1504         # longest BTLE packet, samples
 ZIGBEE_OVERLAP = 17024 + 2048
+ZIGBEE_PREROLL = 4 * 6250   # four time constants of the single-pole DC estimate (alpha = 0.00016)
 
 
 class IqSource:
@@ -265,8 +266,14 @@ class ZigbeeScan:
             while start < len(x):
                 stop = min(start + SEGMENT + ZIGBEE_OVERLAP, len(x))
                 fresh = []
-                for p in rx.process(x[start:stop], first_sample_index=start):
+                # the DC filter restarts with every segment: segments after the first begin four of
+                # its time constants early and leave what they find before `start` to the segment
+                # before (the same rule as ShardedScan, sharded.py ZIGBEE_PREROLL_CH)
+                lead = min(start, ZIGBEE_PREROLL)
+                for p in rx.process(x[start - lead:stop], first_sample_index=start - lead):
                     si = int(p["sample_index"])
+                    if si < start:
+                        continue
                     body = bytes(p["bytes"][:p["len"]])
                     # found again in the overlap: same bytes, first preamble symbol recognised within
                     # 8 symbols (64 samples each) of the earlier run

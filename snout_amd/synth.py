@@ -242,16 +242,48 @@ def oqpsk_modulate(psdu: bytes, tail_symbols: int = 2) -> np.ndarray:
     return (i_s + 1j * q_s).astype(np.complex64)
 
 
+ZB_SLOT = 17408         # samples of one timeslot at 4 Msps: the longest PPDU (133 B = 17 024 samples), tail, guard
+
+
 def zigbee_capture(n_samples: int, channel: int = 11, seed: int = 4, mean_gap: float = 20000.0,
                    sigma: float = 0.05, cfo_max_hz: float = 50e3, fs: float = 4e6,
                    amplitude: float = 1.0, n_packets: Optional[int] = None, min_len: int = 5,
-                   max_len: int = 127, noise: bool = True, tail_guard: int = 4096
-                   ) -> Tuple[np.ndarray, List[TruthPacket]]:
+                   max_len: int = 127, noise: bool = True, tail_guard: int = 4096,
+                   slot_phase: Optional[int] = None) -> Tuple[np.ndarray, List[TruthPacket]]:
     """Single 802.15.4 channel at 4 Msps (2 samples/chip): AWGN + frames with valid FCS separated
-    by exponential gaps (SURVEY §8d cfg #4, per channel)."""
+    by exponential gaps (SURVEY §8d cfg #4, per channel).
+
+    ``slot_phase`` (0 or 1): slotted traffic as in a TSCH schedule -- time is cut into timeslots of
+    ZB_SLOT samples, this channel transmits only in the slots of its phase (even / odd), one frame
+    per used slot, starting at the slot boundary + 64 samples; slots are used with the probability
+    that keeps the mean frame rate of the unslotted model."""
     rng = np.random.default_rng(seed)
     x = np.zeros(n_samples, dtype=np.complex64)
     truth: List[TruthPacket] = []
+    if slot_phase is not None:
+        mean_len = 128.0 * (6 + 0.5 * (min_len + max_len))      # samples of a mean PPDU (2 symbols of 64 per byte)
+        p_use = min(1.0, 2.0 * ZB_SLOT / (mean_gap + mean_len))
+        k = 0
+        while True:
+            start = (2 * k + int(slot_phase)) * ZB_SLOT + 64
+            k += 1
+            if start + ZB_SLOT + tail_guard > n_samples or (n_packets is not None and len(truth) >= n_packets):
+                break
+            if rng.random() >= p_use:
+                continue
+            ln = int(rng.integers(min_len, max_len + 1))
+            psdu = zb_frame(bytes(rng.integers(0, 256, ln - 2, dtype=np.uint8)))
+            wave = oqpsk_modulate(psdu)
+            cfo = rng.uniform(-cfo_max_hz, cfo_max_hz)
+            ph0 = rng.uniform(0, 2 * math.pi)
+            nn = np.arange(wave.size)
+            rot = np.exp(1j * (2 * math.pi * cfo / fs * nn + ph0)).astype(np.complex64)
+            x[start:start + wave.size] += (amplitude * wave * rot).astype(np.complex64)
+            truth.append(TruthPacket(1, channel, start, psdu, {"cfo": cfo}))
+        if noise and sigma > 0:
+            x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+                  ).astype(np.complex64)
+        return x, truth
     pos = int(rng.exponential(mean_gap)) + 512
     while True:
         if n_packets is not None and len(truth) >= n_packets:
@@ -302,7 +334,7 @@ def zigbee_bin_channel(b: int) -> int:
 
 def wideband_capture(proto: int, n_samples: int, seed: int = 3, bins: Optional[Sequence[int]] = None,
                      mean_gap: float = 20000.0, sigma: float = 0.05, cfo_max_hz: float = 50e3,
-                     max_len: int = 127) -> Tuple[np.ndarray, List[TruthPacket]]:
+                     max_len: int = 127, slotted: Optional[bool] = None) -> Tuple[np.ndarray, List[TruthPacket]]:
     """Wideband synthetic capture (SURVEY §8d cfg #3 / #4): every listed channelizer bin carries an
     independent narrowband 4 Msps traffic stream, upsampled by M/2... i.e. to fs = M * 2 MHz, shifted
     to its bin centre (bin b -> b fs / M, wrapping) and summed; AWGN added at the wideband rate.
@@ -321,8 +353,14 @@ def wideband_capture(proto: int, n_samples: int, seed: int = 3, bins: Optional[S
                                   noise=False, cfo_max_hz=cfo_max_hz)
         else:
             ch = zigbee_bin_channel(b)
+            # cfg #4's synthetic 2 MHz raster puts a 2 Mchip/s O-QPSK signal (main lobe +-1.5 MHz) on every
+            # bin: neighbours overlap spectrally, so their traffic is scheduled TSCH-style -- even and odd
+            # bins transmit in alternating timeslots (DESIGN.md deviation 7); `slotted=False` is the
+            # unscheduled model, where colliding neighbours lose frames on any receiver
+            use_slots = (len(bins) > 8) if slotted is None else slotted
             nb, tr = zigbee_capture(n_ch, channel=ch, seed=seed * 1000 + b, mean_gap=mean_gap,
-                                    noise=False, cfo_max_hz=cfo_max_hz, max_len=max_len)
+                                    noise=False, cfo_max_hz=cfo_max_hz, max_len=max_len,
+                                    slot_phase=(b & 1) if use_slots else None)
         wb = _upsample_to_wideband(nb, up)
         rot = np.exp(2j * np.pi * ((b * t) % M) / M).astype(np.complex64)
         x[:wb.size] += wb * rot

@@ -127,3 +127,45 @@ def test_golden_zigbee_fixture_on_gpu():
     with _rx(channel=exp["channel"]) as rx:
         got = rx.process(x, first_sample_index=exp["first_sample_index"])
     _records_equal(got, exp)
+
+
+@pytest.mark.parametrize("seed,gap", [(100, 800.0), (101, 2000.0), (102, 6000.0), (103, 800.0)])
+def test_one_lane_on_the_gpu_is_the_sequential_receiver(oracle, seed, gap):
+    """zb_core >= n: one lane, i.e. GNU Radio's sequential chain (Zigbee_rx/top_block.py:67,69).  The HIP
+    path == the one-lane oracle bit for bit on busy captures, and on the first 2^17 samples == the
+    independently written numpy receiver (tests/zb_sequential_ref.py) record for record."""
+    import zb_sequential_ref as ref
+    n = 1 << 20
+    x, truth = synth.zigbee_capture(n, channel=15, seed=seed, mean_gap=gap, sigma=0.05)
+    with _rx(channel=15, zb_core=1 << 20) as rx:
+        got = rx.process(x)
+        _same_packets(got, oracle.zigbee_segment(x, channel=15, core=1 << 20))
+        assert np.all(got["aux"] == 0) and len(got) >= len(truth) - 1
+        small = rx.process(x[:1 << 17])
+    want, *_ = ref.receive(x[:1 << 17], oracle.zb_mmse_taps(), oracle.zb_chip_map(), channel=15)
+    assert len(small) == len(want) > 5
+    for g, w in zip(small, want):
+        assert int(g["sample_index"]) == w["sample_index"] and int(g["len"]) == w["len"]
+        assert int(g["lqi"]) == w["lqi"] and int(g["crc_ok"]) == w["crc_ok"]
+        assert bytes(g["bytes"][:g["len"]]) == w["bytes"]
+
+
+@pytest.mark.parametrize("seed,gap", [(100, 800.0), (101, 2000.0), (102, 6000.0), (104, 2000.0), (105, 6000.0),
+                                      (106, 800.0)])
+def test_default_lanes_find_the_frames_of_the_sequential_receiver(oracle, seed, gap):
+    """40-90 % channel occupancy: the default lane shape (core 2048) through the HIP path reports the
+    same frames, in the same order, with the same bytes, LQI and FCS verdict as ONE lane -- the resolve
+    pass drops what lane sinks find inside another frame.  Only sample_index may differ, by the phase
+    at which a lane's own timing loop locked (bound asserted: 4 samples = 2 chips)."""
+    x, truth = synth.zigbee_capture(1 << 20, channel=15, seed=seed, mean_gap=gap, sigma=0.05)
+    with _rx(channel=15) as rx:
+        lanes = rx.process(x)
+    with _rx(channel=15, zb_core=1 << 20) as rx:
+        one = rx.process(x)
+    _same_packets(lanes, oracle.zigbee_segment(x, channel=15))
+    assert len(lanes) == len(one) >= len(truth) - 1
+    for f in ("len", "crc_ok", "lqi", "channel"):
+        assert np.array_equal(lanes[f], one[f]), f
+    assert np.array_equal(lanes["bytes"], one["bytes"])
+    d = lanes["sample_index"].astype(np.int64) - one["sample_index"].astype(np.int64)
+    assert np.max(np.abs(d)) <= 4

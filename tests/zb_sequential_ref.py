@@ -110,7 +110,7 @@ def crc16(data: bytes) -> int:
 
 
 def packet_sink(chips: np.ndarray, where: np.ndarray, words, threshold: int = 10):
-    """A.2.4.  Yields (chip index of the first preamble match, PSDU bytes, lqi)."""
+    """A.2.4.  Returns (chip index of the chip that completed the SFD, PSDU bytes, lqi) per frame."""
     words = [int(w) & MASK for w in words]
 
     def dist(reg, s):
@@ -146,6 +146,7 @@ def packet_sink(chips: np.ndarray, where: np.ndarray, words, threshold: int = 10
                     continue
                 break
             ok = dist(reg, 0xA) <= threshold
+            sync = q - 1                              # the chip that completed the SFD
             break
         else:
             # fewer than 32 chips left: consume them (the stream ends inside the frame)
@@ -191,7 +192,7 @@ def packet_sink(chips: np.ndarray, where: np.ndarray, words, threshold: int = 10
             continue
         data = bytes(nibbles[2 * i] | (nibbles[2 * i + 1] << 4) for i in range(len(nibbles) // 2))
         lqi = min(255, (lqi_sum // 8) << 3)
-        frames.append((trigger, data, lqi))
+        frames.append((sync, data, lqi))
         del reg_keep
     return frames
 
@@ -203,11 +204,13 @@ def receive(iq: np.ndarray, taps: np.ndarray, words, channel: int = 11, threshol
     z = dc_removed(d)
     chips, where = clock_recovery(z, taps)
     out = []
-    for trig, data, lqi in packet_sink(chips, where, words, threshold):
+    for sync, data, lqi in packet_sink(chips, where, words, threshold):
         ok = 0
         if len(data) >= 3:
             c = crc16(data[:-2])
             ok = int((c & 0xFF) == data[-2] and (c >> 8) == data[-1])
-        out.append({"sample_index": first_index + int(where[trig]), "channel": channel, "len": len(data),
+        # the record's sample_index: window start of the chip 319 chips before the SFD-completing one,
+        # i.e. the first chip of a regular preamble + SFD (oracle_zigbee.c "sample_index")
+        out.append({"sample_index": first_index + int(where[max(sync - 319, 0)]), "channel": channel, "len": len(data),
                     "lqi": lqi, "crc_ok": ok, "bytes": data})
     return out, d, z, chips
