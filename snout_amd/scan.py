@@ -26,7 +26,6 @@ ZIGBEE_FS = 4e6
 SEGMENT = 1 << 24           # samples per processing segment
 BTLE_OVERLAP = 1504         # longest BTLE packet, samples
 ZIGBEE_OVERLAP = 17024 + 2048
-ZIGBEE_PREROLL = 4 * 6250   # four time constants of the single-pole DC estimate (alpha = 0.00016)
 
 
 class IqSource:
@@ -133,6 +132,32 @@ class WidebandSource(IqSource):
         raise TypeError("a wideband capture is not read per channel: use records(channel)")
 
 
+def _pipelined_segments(proto: int, channel: int, x: np.ndarray, sample_format: int, device: int, **rx_kw):
+    """One channel's capture through the pipelined submit / collect path (what bench.py measures):
+    overlapping segments of SEGMENT samples, two in flight, uploaded chunk by chunk.  Yields the record
+    array of every segment in capture order (duplicates of the overlaps still in)."""
+    import torch
+    from .sharded import ShardedScan
+    dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+    sc = ShardedScan(proto, n_channels=1, channel=channel, seg_len=SEGMENT, device=device,
+                     sample_format=sample_format, **rx_kw)
+
+    def source(a, b):
+        chunk = np.ascontiguousarray(x[a:b])
+        if chunk.dtype == np.complex64:
+            chunk = chunk.view(np.float32)
+        return torch.from_numpy(chunk.reshape(-1)).to(dev)
+    try:
+        sc.start(len(x), source)
+        while sc.active():
+            before = len(sc._parts)
+            sc.step()
+            for rec in sc._parts[before:]:
+                yield rec
+    finally:
+        sc.close()
+
+
 class _Events:
     """Minimal event bus (reference: snout/core/__init__.py:18-58)."""
 
@@ -179,22 +204,17 @@ class BtleScan:
                 self._pkt_no += 1
             return
         x = self.source.read(channel)
-        with SnoutRx(proto=_ffi.PROTO_BTLE, channel=channel, access_addr=self.access_addr,
-                     crc_init=self.crc_init, device=self.device,
-                     sample_format=getattr(self.source, "sample_format", 0)) as rx:
-            start = 0
-            seen_until = -1
-            while start < len(x):
-                stop = min(start + SEGMENT + BTLE_OVERLAP, len(x))
-                for p in rx.process(x[start:stop], first_sample_index=start):
-                    si = int(p["sample_index"])
-                    if si <= seen_until:         # found again in the overlap of the next segment
-                        continue
-                    seen_until = si
-                    self._elapsed = si / BTLE_FS
-                    yield btle_format_line(p, BTLE_FS, self.t0_epoch, self._pkt_no, self.access_addr)
-                    self._pkt_no += 1
-                start += SEGMENT
+        seen_until = -1
+        for rec in _pipelined_segments(_ffi.PROTO_BTLE, channel, x, getattr(self.source, "sample_format", 0),
+                                       self.device, access_addr=self.access_addr, crc_init=self.crc_init):
+            for p in rec:
+                si = int(p["sample_index"])
+                if si <= seen_until:             # found again in the overlap of the next segment
+                    continue
+                seen_until = si
+                self._elapsed = si / BTLE_FS
+                yield btle_format_line(p, BTLE_FS, self.t0_epoch, self._pkt_no, self.access_addr)
+                self._pkt_no += 1
 
     def run(self):
         self.start_time = time.time()
@@ -259,32 +279,22 @@ class ZigbeeScan:
                 yield p
             return
         x = self.source.read(channel)
-        with SnoutRx(proto=_ffi.PROTO_ZIGBEE, channel=channel, device=self.device,
-                     sample_format=getattr(self.source, "sample_format", 0)) as rx:
-            start = 0
-            recent = []                     # (sample_index, bytes) of frames near the segment seam
-            while start < len(x):
-                stop = min(start + SEGMENT + ZIGBEE_OVERLAP, len(x))
-                fresh = []
-                # the DC filter restarts with every segment: segments after the first begin four of
-                # its time constants early and leave what they find before `start` to the segment
-                # before (the same rule as ShardedScan, sharded.py ZIGBEE_PREROLL_CH)
-                lead = min(start, ZIGBEE_PREROLL)
-                for p in rx.process(x[start - lead:stop], first_sample_index=start - lead):
-                    si = int(p["sample_index"])
-                    if si < start:
-                        continue
-                    body = bytes(p["bytes"][:p["len"]])
-                    # found again in the overlap: same bytes, first preamble symbol recognised within
-                    # 8 symbols (64 samples each) of the earlier run
-                    if any(abs(si - s0) <= 8 * 64 + 8 and body == b0 for s0, b0 in recent):
-                        continue
-                    if si >= start + SEGMENT - 8 * 64:
-                        fresh.append((si, body))
-                    self._elapsed = si / ZIGBEE_FS
-                    yield p
-                recent = fresh
-                start += SEGMENT
+        recent = []                     # (sample_index, bytes) of the frames of the segment before
+        # segments after the first start four DC-filter time constants early and leave what they find
+        # there to the segment before (ShardedScan: ZIGBEE_PREROLL_CH, the same rule as the sharded scan)
+        for rec in _pipelined_segments(_ffi.PROTO_ZIGBEE, channel, x, getattr(self.source, "sample_format", 0),
+                                       self.device):
+            fresh = []
+            for p in rec:
+                si = int(p["sample_index"])
+                body = bytes(p["bytes"][:p["len"]])
+                # found again in the overlap: same bytes, the two runs' timing loops locked a few samples apart
+                if any(abs(si - s0) <= 8 * 64 + 8 and body == b0 for s0, b0 in recent):
+                    continue
+                fresh.append((si, body))
+                self._elapsed = si / ZIGBEE_FS
+                yield p
+            recent = fresh
 
     def run(self):
         for ch in self.channels:
