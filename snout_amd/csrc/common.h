@@ -121,7 +121,7 @@ struct PfbZbTarget {
 struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
-    uint32_t grid_blocks = 768;      // persistent grid (256 CUs x 3 workgroups: 128 VGPRs, 36 KB LDS)
+    uint32_t grid_blocks = 0;        // persistent grid; 0 = what is RESIDENT at once (see PfbCtx::run), else SNOUT_PFB_BLOCKS
     DevBuf d_proto, d_tw, d_tw5, d_y;
     int init(uint32_t M);
     void destroy();
@@ -148,6 +148,11 @@ struct ZbCtx {
     DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
     double d64 = 0, dcore = 0, dfirst = 0;
     uint64_t nsb = 0;
+    // chunked front end of a long narrowband segment: clock recovery of chunk c runs on `aux` while the
+    // discriminator of chunk c + 1 runs on the caller's stream (HBM-bound beside VALU-bound)
+    static constexpr int kFrontChunks = 4;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_disc[kFrontChunks] = {nullptr, nullptr, nullptr, nullptr}, ev_aux = nullptr;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
              uint32_t warmup);

@@ -33,6 +33,21 @@
 
 namespace snout {
 
+#ifdef SNOUT_PFB_STAMPS
+// Diagnostic build only (tools/pfb_stamps.py): cycles each phase of the tile loop takes, per wave, summed
+// over the tiles of a workgroup: [block][wave][slot] (s_memtime deltas; slot 7: shader clock in kHz), and
+// per block its start / end time (s_memrealtime, 100 MHz) and hardware ids.
+__device__ unsigned long long g_pfb_stamps[1024 * 5 * 8];
+__device__ unsigned long long g_pfb_times[1024 * 4];
+#define STAMP(k)                                                                       \
+    do {                                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                 \
+        st_acc[k] += now_ - st_last; st_last = now_;                                   \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct cf { float re, im; };
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -247,6 +262,11 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int i = 0; i < (FUSE3B ? M2 : 1); i++) carry5[i] = cf{0.0f, 0.0f};
 
+#ifdef SNOUT_PFB_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef SNOUT_PFB_STAGGER
     // Workgroups that share a CU start together and would run their LDS-heavy and VALU-heavy phases
     // in step; delay every other round of the grid by a fraction of a tile.
@@ -258,7 +278,9 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         if (t < OV4) reinterpret_cast<float4*>(xs)[t] = keep;
 #pragma unroll
         for (int k = 0; k < NPRE; k++) reinterpret_cast<float4*>(xs)[OV4 + t + k * NT] = iq_pair_cvt<FMT>(pre[k]);
+        STAMP(0);
         lds_barrier();
+        STAMP(1);
 #if !defined(SNOUT_PFB_LATE_PREFETCH) && !defined(SNOUT_ABL_NOGLOBAL)
         if (tile + 1u < t_last) {
             const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
@@ -337,7 +359,9 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #endif
         }
         if (t < OV4) keep = reinterpret_cast<const float4*>(xs)[NEW4 + t];   // next tile's overlap
+        STAMP(2);
         lds_barrier();
+        STAMP(3);
 #ifdef SNOUT_PFB_LATE_PREFETCH
         // the next tile's samples are requested only now: they are not live across the FIR (its
         // register peak), and the two FFT passes are time enough for them to land
@@ -382,7 +406,9 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             }
         }
 #endif
+        STAMP(4);
         lds_barrier();
+        STAMP(5);
 
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
         //      Fused: in place, channel k = k1 + M1 k2 ends up in slot M2 k1 + k2 of row m.
@@ -571,13 +597,37 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             }
         }
         // the next tile's FIR writes us only after the staging barrier, i.e. after every read above
+        STAMP(6);
     }
+#ifdef SNOUT_PFB_STAMPS
+    if ((t & 63) == 0 && blockIdx.x < 1024) {
+        st_acc[7] = (__builtin_amdgcn_s_memtime() - st_t0) * 100000ull / (__builtin_amdgcn_s_memrealtime() - st_r0 + 1ull);
+        for (int k = 0; k < 8; k++) g_pfb_stamps[(blockIdx.x * 5 + (t >> 6)) * 8 + k] = st_acc[k];
+        if (t == 0) {
+            g_pfb_times[blockIdx.x * 4 + 0] = st_r0;
+            g_pfb_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            g_pfb_times[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+            g_pfb_times[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        }
+    }
+#endif
 }
 
 // =============================================================================================
 // Host side
 // =============================================================================================
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+#ifdef SNOUT_PFB_STAMPS
+extern "C" int snout_debug_pfb_times(unsigned long long* out, uint32_t n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfb_times), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+}
+extern "C" int snout_debug_pfb_stamps(unsigned long long* out, uint32_t n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfb_stamps), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+}
+#endif
 
 int PfbCtx::init(uint32_t M_)
 {
@@ -624,10 +674,16 @@ int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16
         else if (fmt == kFmtSc16) SNOUT_PFB_F(MM, FU, kFmtSc16, Y, YS, PL, PS);                       \
         else SNOUT_PFB_F(MM, FU, kFmtCf32, Y, YS, PL, PS);                                            \
     } while (0)
-    // persistent workgroups (3 per CU by registers), each walks a contiguous range of tiles
+    // Persistent workgroups, each walks a contiguous range of tiles: the grid must be what is RESIDENT at
+    // once, or the rest runs as a second round on a nearly empty chip.  M = 40: a workgroup is 5 waves,
+    // at 4 wave slots per SIMD (105..128 VGPRs) the hardware's cyclic wave placement fits exactly TWO of
+    // them per CU, not the three that 16 slots / 5 waves suggests (census with s_memrealtime stamps,
+    // tools/pfb_stamps.py: 512 of 768 workgroups started at once, 2 on every CU, the other 256 after
+    // them; a 514-workgroup grid takes 5.9 ms instead of 3.8).
     if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
-        const uint32_t tpw = cdiv(n_tiles, grid_blocks), nwg = cdiv(n_tiles, tpw);
+        const uint32_t blocks40 = grid_blocks ? grid_blocks : 512u;
+        const uint32_t tpw = cdiv(n_tiles, blocks40), nwg = cdiv(n_tiles, tpw);
         if (planes16)
             SNOUT_PFB(40, true, (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
@@ -637,7 +693,7 @@ int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16
         // 256-thread workgroups: four per CU fit (128 VGPRs, 29 KB LDS).  The fused 802.15.4 variant
         // is built for three waves per SIMD instead (148 VGPRs, nothing spilled; at 128 it spilled 15
         // registers inside the tile loop): three workgroups per CU, 1.05 ms instead of 1.18 ms.
-        const uint32_t blocks16 = grid_blocks == 768u ? (zbt ? 768u : 1024u) : grid_blocks;
+        const uint32_t blocks16 = grid_blocks ? grid_blocks : (zbt ? 768u : 1024u);     // 4-wave workgroups place evenly
         const uint32_t tpw = cdiv(n_tiles, blocks16), nwg = cdiv(n_tiles, tpw);
         if (zbt) {
             // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
