@@ -148,11 +148,6 @@ struct ZbCtx {
     DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
     double d64 = 0, dcore = 0, dfirst = 0;
     uint64_t nsb = 0;
-    // chunked front end of a long narrowband segment: clock recovery of chunk c runs on `aux` while the
-    // discriminator of chunk c + 1 runs on the caller's stream (HBM-bound beside VALU-bound)
-    static constexpr int kFrontChunks = 4;
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_disc[kFrontChunks] = {nullptr, nullptr, nullptr, nullptr}, ev_aux = nullptr;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
              uint32_t warmup);

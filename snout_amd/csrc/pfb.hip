@@ -125,6 +125,12 @@ __device__ __forceinline__ void lds_barrier()
 #define SNOUT_PFB_PKFIR 1
 #define SNOUT_PFB_NOREAD2 1
 #endif
+#ifndef SNOUT_PFB_PRIO_FIR
+#define SNOUT_PFB_PRIO_FIR 0
+#endif
+#ifndef SNOUT_PFB_PRIO_FFT
+#define SNOUT_PFB_PRIO_FFT 1
+#endif
 #ifndef SNOUT_PFB_WPE
 #define SNOUT_PFB_WPE 4
 #endif
@@ -215,16 +221,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #endif
 
     static_assert((T * M2) % NT == 0 && T % 64 == 0, "pass 3a: whole rounds, wave-uniform n2");
-    float tw3a[T * M2 / NT][2 * M1];               // W_M^{n2 k1} of this wave's n2 per round (scalar registers)
-#pragma unroll
-    for (int rnd = 0; rnd < T * M2 / NT; rnd++) {
-        const int n2u = __builtin_amdgcn_readfirstlane((t + rnd * NT) / T);
-#pragma unroll
-        for (int k1 = 0; k1 < M1; k1++) {
-            const int j = (n2u * k1) % M;          // < M: n2 k1 <= (M2-1)(M1-1) < M for both geometries
-            tw3a[rnd][2 * k1] = twM[2 * j];
-            tw3a[rnd][2 * k1 + 1] = twM[2 * j + 1];
-        }
+    // W_M^{n2 k1} by row n2: a wave of pass 3a reads its row as 2 M1 / 4 wave-uniform 16-byte LDS reads per
+    // tile (broadcast reads: conflict-free, and no register is held across the other phases)
+    __shared__ float4 tw3_s[M2 * (2 * M1 / 4)];
+    for (int i = t; i < M2 * 2 * M1; i += NT) {
+        const int n2i = i / (2 * M1), k1 = (i % (2 * M1)) >> 1, j = (n2i * k1) % M;    // n2 k1 < M for both geometries
+        reinterpret_cast<float*>(tw3_s)[i] = twM[2 * j + (i & 1)];
     }
 
     const uint32_t t_begin = blockIdx.x * tiles_per_wg;
@@ -281,6 +283,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         STAMP(0);
         lds_barrier();
         STAMP(1);
+        // The FIR is the throughput phase (128 independent packed FMAs per thread); the FFT passes and the
+        // slicer are dependency chains with LDS round trips in them, and the workgroup waits for their
+        // slowest wave at every barrier.  The SIMD arbitrates by priority, then age: with equal priority
+        // another workgroup's FIR waves take the issue slots the FFT waves need between their stalls.
+        // FIR at priority 0, everything else at 1: -10 % on the whole kernel (tools/pfb_ab.py).
+        __builtin_amdgcn_s_setprio(SNOUT_PFB_PRIO_FIR);
 #if !defined(SNOUT_PFB_LATE_PREFETCH) && !defined(SNOUT_ABL_NOGLOBAL)
         if (tile + 1u < t_last) {
             const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
@@ -329,21 +337,28 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #elif defined(SNOUT_PFB_PKFIR)
             // (re, im) of one output advance together in v_pk_fma_f32; the tap is broadcast to both halves
             // by op_sel from a register PAIR holding two consecutive taps, so the 16 taps take 16
-            // registers (the compiler's own packing keeps every tap twice: 32)
+            // registers (the compiler's own packing keeps every tap twice: 32).  Four outputs advance
+            // side by side, tap by tap: consecutive instructions never depend on each other (the
+            // two-chain order the compiler picks needs an s_nop between most of them).
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                v2f acc;
-                {
-                    const v2f x0 = {w[i].x, w[i].y};
-                    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc) : "v"(hp[0]), "v"(x0));
+            for (int i0 = 0; i0 < 8; i0 += 4) {
+                v2f acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const v2f x0 = {w[i0 + j].x, w[i0 + j].y};
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc[j]) : "v"(hp[0]), "v"(x0));
                 }
 #pragma unroll
                 for (int p = 1; p < P; p++) {
-                    const v2f xv = {w[i + p].x, w[i + p].y};
-                    if (p & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(hp[p >> 1]), "v"(xv));
-                    else       asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(hp[p >> 1]), "v"(xv));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const v2f xv = {w[i0 + j + p].x, w[i0 + j + p].y};
+                        if (p & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(xv));
+                        else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(xv));
+                    }
                 }
-                us[(e + 2 * (8 * grp + i)) * ROW + r] = make_float2(acc.x, acc.y);
+#pragma unroll
+                for (int j = 0; j < 4; j++) us[(e + 2 * (8 * grp + i0 + j)) * ROW + r] = make_float2(acc[j].x, acc[j].y);
             }
 #else
 #pragma unroll
@@ -360,6 +375,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         }
         if (t < OV4) keep = reinterpret_cast<const float4*>(xs)[NEW4 + t];   // next tile's overlap
         STAMP(2);
+        __builtin_amdgcn_s_setprio(SNOUT_PFB_PRIO_FFT);
         lds_barrier();
         STAMP(3);
 #ifdef SNOUT_PFB_LATE_PREFETCH
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int rnd = 0; rnd < T * M2 / NT; rnd++) {
             // T is a multiple of 64, so n2 is the same for a whole wave: its twiddles W_M^{n2 k1} are
-            // wave-uniform values held in scalar registers (tw3a, loaded before the tile loop)
+            // wave-uniform: one row of tw3_s
             const int it = t + rnd * NT;
             const int m = it % T, n2 = __builtin_amdgcn_readfirstlane(it / T);
             cf a[M1], A[M1];
@@ -393,6 +409,12 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
                 a[n1] = cf{v.x, v.y};
             }
             if constexpr (M1 == 8) dft8(a, A); else dft4(a, A);
+            float tw3a[2 * M1];
+#pragma unroll
+            for (int q = 0; q < 2 * M1 / 4; q++) {
+                const float4 v = tw3_s[n2 * (2 * M1 / 4) + q];
+                tw3a[4 * q] = v.x; tw3a[4 * q + 1] = v.y; tw3a[4 * q + 2] = v.z; tw3a[4 * q + 3] = v.w;
+            }
             us[m * ROW + n2] = make_float2(A[0].re, A[0].im);           // k1 = 0: W^0
             if (n2 == 0) {                                              // uniform: W^0 throughout
 #pragma unroll
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             } else {
 #pragma unroll
                 for (int k1 = 1; k1 < M1; k1++) {
-                    const cf v = cmul_tw(A[k1], tw3a[rnd][2 * k1], tw3a[rnd][2 * k1 + 1]);
+                    const cf v = cmul_tw(A[k1], tw3a[2 * k1], tw3a[2 * k1 + 1]);
                     us[m * ROW + M2 * k1 + n2] = make_float2(v.re, v.im);
                 }
             }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, u
                                                   uint64_t iq_stride, uint64_t d_stride, uint64_t nsb,
                                                   const float* __restrict__ atan_tab,
                                                   const double* __restrict__ iir_w,
-                                                  float* __restrict__ d, double* __restrict__ S, uint32_t blk0)
+                                                  float* __restrict__ d, double* __restrict__ S)
 {
     __shared__ float tab[257];
     __shared__ double wts[64];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, u
     // are taken by wave c mod 4 from a double-buffered copy of the chunk's values while the other
     // waves go on to the next chunk.
     for (uint32_t c = 0; c < kDiscChunks; c++) {
-        const uint64_t chunk = (uint64_t)(blockIdx.x + blk0) * kDiscChunks + c;
+        const uint64_t chunk = (uint64_t)blockIdx.x * kDiscChunks + c;
         if (chunk * 1024u >= d_stride) break;
         const uint64_t t0 = chunk * 1024u + 4u * threadIdx.x;      // this thread's 4 samples
         float ang[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, u
 __global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S, uint64_t nsb,
                                                    uint32_t lanes_per_slot, uint32_t total_lanes,
                                                    uint32_t core, uint32_t warmup, double d64,
-                                                   double* __restrict__ Lblk, uint32_t g0)
+                                                   double* __restrict__ Lblk)
 {
-    const uint32_t g = g0 + blockIdx.x * 256u + threadIdx.x;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= total_lanes) return;
     const uint32_t slot = g / lanes_per_slot, li = g % lanes_per_slot;
     const uint64_t b0 = li == 0 ? 0ull : ((uint64_t)li * core - warmup) / 64u;
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S,
 // decayed below 2^-60; see the oracle): one thread per lane, no dependence between lanes.
 __global__ __launch_bounds__(256) void zb_iir_scan(const double* __restrict__ Lblk, uint32_t lanes_per_slot,
                                                   uint32_t total_lanes, uint32_t window, double dfirst,
-                                                  double dcore, double* __restrict__ lp_in, uint32_t g0)
+                                                  double dcore, double* __restrict__ lp_in)
 {
-    const uint32_t g = g0 + blockIdx.x * 256u + threadIdx.x;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= total_lanes) return;
     const uint32_t li = g % lanes_per_slot;
     const double* L = Lblk + (g - li);
@@ -191,13 +191,13 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     const double* __restrict__ lp_in,
     uint32_t* __restrict__ TR, ZbLaneOut* __restrict__ lane_out, uint32_t* __restrict__ cand_keys,
     float* __restrict__ soft_z, float* __restrict__ soft_chips, uint32_t soft_lane, uint32_t soft_cap,
-    uint32_t* __restrict__ soft_n, uint32_t blk0)
+    uint32_t* __restrict__ soft_n)
 {
     // kMmWaves independent waves per workgroup share one copy of the tap table (LDS decides how many
     // waves a CU holds: 10.5 KB of rows per wave + 4.1 KB of taps per workgroup)
     __shared__ float zb_all[kMmWaves * 64 * kZRow];
     __shared__ float4 tapsA[129], tapsB[129];
-    const uint32_t l = threadIdx.x & 63u, w = (blockIdx.x + blk0) * kMmWaves + (threadIdx.x >> 6);
+    const uint32_t l = threadIdx.x & 63u, w = blockIdx.x * kMmWaves + (threadIdx.x >> 6);
     float* zb = &zb_all[(threadIdx.x >> 6) * 64u * kZRow];
     for (uint32_t i = threadIdx.x; i < 129u; i += kMmWaves * 64u) {
         tapsA[i] = make_float4(mmse[i * 8u + 0u], mmse[i * 8u + 1u], mmse[i * 8u + 2u], mmse[i * 8u + 3u]);
@@ -1083,19 +1083,11 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
     SNOUT_HIP(hipMemcpy(d_atan.p, atan_tab.data(), 257 * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_mmse.p, kMmseTapsHost, 129 * 8 * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_slot_channel.p, slot_channel_, n_slots * 2, hipMemcpyHostToDevice));
-    if (n_slots == 1u && !getenv("SNOUT_ZB_NO_CHUNKS")) {      // chunked front end of long segments (enqueue_front)
-        SNOUT_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        for (auto& e : ev_disc) SNOUT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        SNOUT_HIP(hipEventCreateWithFlags(&ev_aux, hipEventDisableTiming));
-    }
     return 0;
 }
 
 void ZbCtx::destroy()
 {
-    if (aux) { (void)hipStreamDestroy(aux); aux = nullptr; }
-    for (auto& e : ev_disc) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    if (ev_aux) { (void)hipEventDestroy(ev_aux); ev_aux = nullptr; }
     d_atan.release(); d_mmse.release(); d_slot_channel.release();
     d_d.release(); d_TR.release(); d_lane_out.release(); d_cand.release(); d_lane_u32.release();
     d_stream.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
@@ -1200,7 +1192,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     hipLaunchKernelGGL(zb_mm<true>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, nullptr, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
-                       sz, sc, lane, (uint32_t)kSoftCap, sn, 0u);
+                       sz, sc, lane, (uint32_t)kSoftCap, sn);
     SNOUT_HIP(hipDeviceSynchronize());
     uint32_t nch = 0;
     SNOUT_HIP(hipMemcpy(&nch, sn, 4, hipMemcpyDeviceToHost));
@@ -1233,62 +1225,25 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
 {
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k0, st));
     if (n < 9u) return 0;   // no interpolator window fits: nothing to launch
-    auto discrim = [&](uint32_t blk0, uint32_t nblk, hipStream_t q) {
+    if (d_iq) {             // otherwise the fused channelizer has already written d and S
 #define SNOUT_ZBD(F)                                                                                  \
-    hipLaunchKernelGGL(zb_discrim<F>, dim3(nblk, n_slots), dim3(256), 0, q, d_iq, n, iq_stride, d_stride, nsb, \
-                       d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(), d_S.as<double>(), blk0)
+    hipLaunchKernelGGL(zb_discrim<F>, dim3(cdiv(d_stride, 1024 * kDiscChunks), n_slots), dim3(256), 0, st, d_iq, n, \
+                       iq_stride, d_stride, nsb, d_atan.as<float>(), d_iirw.as<double>(), d_d.as<float>(), \
+                       d_S.as<double>())
         if (fmt == kFmtSc8) SNOUT_ZBD(kFmtSc8);
         else if (fmt == kFmtSc16) SNOUT_ZBD(kFmtSc16);
         else SNOUT_ZBD(kFmtCf32);
 #undef SNOUT_ZBD
-    };
-    // carry-in + clock recovery of the lanes [g0, g1) (g0 a multiple of 256 = one zb_mm workgroup)
-    auto lanes = [&](uint32_t g0, uint32_t g1, hipStream_t q) {
-        const uint32_t nb = cdiv(g1 - g0, 256);
-        hipLaunchKernelGGL(zb_iir_fold, dim3(nb), dim3(256), 0, q, d_S.as<double>(), nsb,
-                           lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>(), g0);
-        hipLaunchKernelGGL(zb_iir_scan, dim3(nb), dim3(256), 0, q, d_Lblk.as<double>(),
-                           lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
-                           d_lp_in.as<double>(), g0);
-        hipLaunchKernelGGL(zb_mm<false>, dim3(nb), dim3(kMmWaves * 64), 0, q, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
-                           total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
-                           d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
-                           (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr, g0 / 256u);
-    };
-    static_assert(kMmWaves * 64 == 256, "lane ranges are cut at zb_mm workgroups");
-    const uint32_t disc_blocks = cdiv(d_stride, 1024 * kDiscChunks);
-    // A long single-channel segment is cut into chunks: the discriminator (HBM-bound: 8 B read + 4 B
-    // written per sample) of chunk c + 1 runs on the caller's stream while the carry-in and the clock
-    // recovery (VALU-bound) of chunk c run on `aux`.  A lane reads d up to 8 samples past its core, so the
-    // lanes of a chunk stop one lane short of the samples discriminated so far; results do not depend
-    // on the cut (every kernel works per lane).
-    const uint64_t unit = 256ull * core;                               // samples of one zb_mm workgroup of lanes
-    const bool chunked = d_iq && n_slots == 1u && aux && n >= 16ull * unit;
-    if (!chunked) {
-        if (d_iq) discrim(0u, disc_blocks, st);     // otherwise the fused channelizer has already written d and S
-        lanes(0u, total_lanes, st);
-        SNOUT_HIP(hipGetLastError());
-        return 0;
     }
-    const uint64_t per = ((n + kFrontChunks - 1) / kFrontChunks + unit - 1) / unit * unit;   // samples per chunk
-    uint32_t blk_done = 0, g_done = 0;
-    SNOUT_HIP(hipEventRecord(ev_aux, st));                              // aux starts behind whatever precedes on st
-    SNOUT_HIP(hipStreamWaitEvent(aux, ev_aux, 0));
-    for (int c = 0; c < kFrontChunks; c++) {
-        const bool last = c == kFrontChunks - 1 || (uint64_t)(c + 1) * per >= n;
-        const uint64_t a1 = last ? d_stride : (uint64_t)(c + 1) * per;  // samples discriminated after this chunk
-        const uint32_t blk1 = last ? disc_blocks : (uint32_t)(a1 / (1024ull * kDiscChunks));
-        if (blk1 > blk_done) discrim(blk_done, blk1 - blk_done, st);
-        blk_done = blk1;
-        SNOUT_HIP(hipEventRecord(ev_disc[c], st));
-        SNOUT_HIP(hipStreamWaitEvent(aux, ev_disc[c], 0));
-        const uint32_t g1 = last ? total_lanes : (uint32_t)(a1 / core) - 256u;   // whole workgroups, one short
-        if (g1 > g_done) lanes(g_done, g1, aux);
-        g_done = g1 > g_done ? g1 : g_done;
-        if (last) break;
-    }
-    SNOUT_HIP(hipEventRecord(ev_aux, aux));
-    SNOUT_HIP(hipStreamWaitEvent(st, ev_aux, 0));                       // the tail follows on st
+    hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
+                       lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
+    hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
+                       lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
+                       d_lp_in.as<double>());
+    hipLaunchKernelGGL(zb_mm<false>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
+                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
+                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
+                       (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
     SNOUT_HIP(hipGetLastError());
     return 0;
 }
