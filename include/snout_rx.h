@@ -166,6 +166,15 @@ int  snout_rx_profile(snout_rx* h, snout_rx_prof* out);
  * segments, oldest first.  Read after the fact so a pipelined run is not perturbed. */
 int  snout_rx_profile_history(snout_rx* h, float* ms, uint32_t cap, uint32_t* n_out);
 
+/* Multi-GPU gather (no reference counterpart: the reference has one radio): copy the
+ * device copy of the records of the segment collected last into an exchange buffer on the device, in the
+ * wire format = the first `width` bytes (a multiple of 16, 32..160) of every 160-byte record, on
+ * `hip_stream`.  Records with sample_index < own_from (found in a segment's pre-roll: another segment
+ * reports them) get sample_index = 2^62 and are dropped by the gather's sort.  *n_packed = records
+ * written (<= dst_cap; SNOUT_EOVERFLOW if the segment had more). */
+int  snout_rx_pack_last_records(snout_rx* h, void* dst_dev, uint64_t dst_cap, uint32_t width, uint64_t own_from,
+                                void* hip_stream, uint64_t* n_packed);
+
 /* Measurement aid (bench.py, SURVEY.md §8d "measured-copy-peak"): read-only streaming rate, in GB/s,
  * of `bytes` bytes of device memory at `dev` (a fully coalesced 16-byte-per-lane grid-stride read
  * kernel, `reps` timed launches after one warm-up, HIP events on `hip_stream`).  Not part of the

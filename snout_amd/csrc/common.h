@@ -103,6 +103,10 @@ struct BtleCtx {
 };
 
 
+// records.hip: the first `width` bytes of n 160-byte records -> dst (n x width bytes); records whose
+// sample_index is below own_from get sample_index = 2^62 ("disowned": the gather's sort drops them)
+int launch_pack_records(const snout_pkt* src, uint64_t n, void* dst, uint32_t width, uint64_t own_from, hipStream_t st);
+
 void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fixed, uint32_t n_limit,
                         uint32_t clamp, uint32_t* tile_sums, uint32_t* tile_over, uint32_t n_tiles,
                         hipStream_t st);

@@ -519,6 +519,23 @@ int snout_rx_last_records_dev(snout_rx* h, const snout_pkt** recs_dev, uint64_t*
     return SNOUT_OK;
 }
 
+int snout_rx_pack_last_records(snout_rx* h, void* dst_dev, uint64_t dst_cap, uint32_t width, uint64_t own_from,
+                               void* hip_stream, uint64_t* n_packed)
+{
+    if (!h || !n_packed || (!dst_dev && dst_cap) || width < 32u || width > sizeof(snout_pkt) || (width & 15u)) return SNOUT_EINVAL;
+    *n_packed = 0;
+    if (!h->last) { set_last_error("no collected segment"); return SNOUT_EINVAL; }
+    const uint64_t np = h->last->n_pkts;
+    const uint64_t m = np < dst_cap ? np : dst_cap;
+    SNOUT_HIP(hipSetDevice(h->device));
+    if (m) {
+        if (int rc = launch_pack_records(h->last->d_out.as<snout_pkt>(), m, dst_dev, width, own_from, (hipStream_t)hip_stream))
+            return rc;
+    }
+    *n_packed = m;
+    return np > dst_cap ? SNOUT_EOVERFLOW : SNOUT_OK;
+}
+
 int snout_rx_collect(snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out)
 {
     if (!n_out || (!out && cap)) return SNOUT_EINVAL;

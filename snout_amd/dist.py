@@ -243,10 +243,12 @@ class AsyncRecordGather:
         slot["fill"], slot["n"], slot["rest"] = 0, 0, []
         self.cur = slot
 
-    def append(self, rec: np.ndarray, dev_ptr: int = 0, own_from: int = 0) -> None:
-        """Add the records of one collected segment.  ``dev_ptr``: device address of the same records
-        (SnoutRx.last_records_device()); on a GPU they are then packed straight from device memory.
-        Records with sample_index < ``own_from`` belong to another segment and are dropped."""
+    def append(self, rec: np.ndarray, dev_ptr: int = 0, own_from: int = 0, rx=None) -> None:
+        """Add the records of one collected segment.  ``rx``: the receiver handle that just collected
+        them -- on a GPU its library then packs them from the device copy into the exchange buffer with
+        ONE kernel launch (``snout_rx_pack_last_records``); ``dev_ptr`` (SnoutRx.last_records_device())
+        does the same with torch operations.  Records with sample_index < ``own_from`` belong to another
+        segment and are dropped."""
         torch = self.torch
         slot = self.cur
         n = int(rec.size)
@@ -264,6 +266,11 @@ class AsyncRecordGather:
                 slot["n"] -= (n - take) - r.size
             slot["rest"].append(r)
         if take == 0:
+            return
+        if self.on_gpu and rx is not None:
+            dst = slot["send"].data_ptr() + (1 + slot["fill"]) * W
+            rx.pack_last_records(dst, take, W, int(own_from), self.stream.cuda_stream)
+            slot["fill"] += take
             return
         with self._ctx():
             view = slot["send"][(1 + slot["fill"]) * W:(1 + slot["fill"] + take) * W].view(take, W)

@@ -160,6 +160,14 @@ class SnoutRx:
         _ffi.check(self._lib.snout_rx_last_records_dev(self._h, C.byref(ptr), C.byref(n)))
         return (ptr.value or 0), int(n.value)
 
+    def pack_last_records(self, dst_ptr: int, dst_cap: int, width: int, own_from: int, stream: int) -> int:
+        """Pack the device copy of the last collected segment's records into an exchange buffer on the
+        device (wire format: the first ``width`` bytes of each record), on ``stream``; one launch."""
+        n = C.c_uint64(0)
+        _ffi.check(self._lib.snout_rx_pack_last_records(self._h, C.c_void_p(dst_ptr), dst_cap, width, own_from,
+                                                        C.c_void_p(stream), C.byref(n)), allow_overflow=True)
+        return int(n.value)
+
     def soft(self, stage: int, channel_slot: int = 0, cap: int = 0) -> np.ndarray:
         cap = cap or (1 << 24)
         out = np.zeros(cap, dtype=np.float32)

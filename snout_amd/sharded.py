@@ -112,7 +112,7 @@ class ShardedScan:
             own = self._own_from[j] if self.preroll else 0
             if self._sink is not None:
                 rec = rx.collect(copy=False)                    # segments of a handle complete in order
-                self._sink.append(rec, rx.last_records_device()[0], own_from=own)
+                self._sink.append(rec, own_from=own, rx=rx)
                 if self._sink.on_gpu:
                     ev = torch.cuda.Event()
                     ev.record(self._sink.stream)
