@@ -545,7 +545,7 @@ def main():
                                                   "decoded_crc_ok_per_gpu", "expected_crc_ok_per_gpu")}
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
-            r5 = run_cfg5(max(3, min(args.steps, 5)), 1, device, 0, 1, seconds=args.seconds)
+            r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, 0, 1, seconds=args.seconds)
             others["cfg5"] = {f: r5[f] for f in ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu",
                                                  "records_on_rank0", "decoded_crc_ok", "expected_crc_ok", "frac",
                                                  "achieved_GBps", "sharding")}
