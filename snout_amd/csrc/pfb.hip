@@ -172,7 +172,7 @@ template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, N
 // therefore also computes the tile after its range, without emitting that tile's own bits.
 // FMT: input sample format (iq_fmt.h); integer samples are converted as they are fetched.
 template <int M, bool FUSED, int FMT>
-__global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu((FUSED && M == 16) ? SNOUT_PFB_WPE_ZB : SNOUT_PFB_WPE))) void pfb_channelize(
+__device__ __forceinline__ void pfb_body(
     const void* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
@@ -188,13 +188,13 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     static_assert(NEW4 % NT == 0 && OV4 <= NT, "staging shape");
     constexpr int NPRE = NEW4 / NT;                // new pairs each thread stages per tile
     __shared__ float2 xs[SPAN];                    // input span of the current tile
-    __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
     constexpr bool ZB = FUSED && M == 16;          // fused 802.15.4 discriminator epilogue
 #ifdef SNOUT_PFB_NO_FUSE3B
     constexpr bool FUSE3B = false;
 #else
     constexpr bool FUSE3B = FUSED && M == 40;      // BTLE: pass 3b decides the hard bits in registers
 #endif
+    __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
     constexpr int DLROW = T + 1;                   // padded row of the tile's d values (S_j reads)
     static_assert(!ZB || (M * DLROW <= 2 * SPAN && T == 128 && NT == 256), "d tile reuses the input span");
     __shared__ float atan_s[ZB ? 257 : 1];
@@ -274,24 +274,18 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
     // in step; delay every other round of the grid by a fraction of a tile.
     for (uint32_t i = 0; i < (blockIdx.x / 256u) % 3u; i++) __builtin_amdgcn_s_sleep(SNOUT_PFB_STAGGER);
 #endif
-    for (uint32_t tile = t_first; tile < t_last; tile++) {
-        const uint64_t m0 = (uint64_t)tile * T;
+    // The phases of one tile, as closures over the kernel's state (inlined); `us` is the FIR-output /
+    // FFT buffer they work on.
+    auto do_stage = [&]() {
         // ---- 1. stage: overlap to the front, new samples behind it
         if (t < OV4) reinterpret_cast<float4*>(xs)[t] = keep;
 #pragma unroll
         for (int k = 0; k < NPRE; k++) reinterpret_cast<float4*>(xs)[OV4 + t + k * NT] = iq_pair_cvt<FMT>(pre[k]);
-        STAMP(0);
-        lds_barrier();
-        STAMP(1);
-        // The FIR is the throughput phase (128 independent packed FMAs per thread); the FFT passes and the
-        // slicer are dependency chains with LDS round trips in them, and the workgroup waits for their
-        // slowest wave at every barrier.  The SIMD arbitrates by priority, then age: with equal priority
-        // another workgroup's FIR waves take the issue slots the FFT waves need between their stalls.
-        // FIR at priority 0, everything else at 1: -10 % on the whole kernel (tools/pfb_ab.py).
-        __builtin_amdgcn_s_setprio(SNOUT_PFB_PRIO_FIR);
+    };
+    auto do_prefetch = [&](uint32_t nxt) {       // request tile nxt's new samples (raw, into registers)
 #if !defined(SNOUT_PFB_LATE_PREFETCH) && !defined(SNOUT_ABL_NOGLOBAL)
-        if (tile + 1u < t_last) {
-            const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
+        if (nxt < t_last) {
+            const uint64_t in1 = (uint64_t)nxt * NEW + 2ull * OV4;   // first new sample of the next tile
             if (in1 + NEW <= n) {                 // uniform: all NEW samples exist, no per-lane range tests
 #pragma unroll
                 for (int k = 0; k < NPRE; k++) pre[k] = iq_pair_raw<FMT>(x, in1 + 2ull * (uint64_t)(t + k * NT));
@@ -301,7 +295,8 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             }
         }
 #endif
-
+    };
+    auto do_fir = [&]() {
         // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product
         {
             const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
@@ -374,25 +369,8 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
 #endif
         }
         if (t < OV4) keep = reinterpret_cast<const float4*>(xs)[NEW4 + t];   // next tile's overlap
-        STAMP(2);
-        __builtin_amdgcn_s_setprio(SNOUT_PFB_PRIO_FFT);
-        lds_barrier();
-        STAMP(3);
-#ifdef SNOUT_PFB_LATE_PREFETCH
-        // the next tile's samples are requested only now: they are not live across the FIR (its
-        // register peak), and the two FFT passes are time enough for them to land
-        if (tile + 1u < t_last) {
-            const uint64_t in1 = (uint64_t)(tile + 1u) * NEW + 2ull * OV4;   // first new sample of the next tile
-            if (in1 + NEW <= n) {                 // uniform: all NEW samples exist, no per-lane range tests
-#pragma unroll
-                for (int k = 0; k < NPRE; k++) pre[k] = iq_pair_raw<FMT>(x, in1 + 2ull * (uint64_t)(t + k * NT));
-            } else {
-#pragma unroll
-                for (int k = 0; k < NPRE; k++) pre[k] = load_pair(in1 + 2ull * (uint64_t)(t + k * NT));
-            }
-        }
-#endif
-
+    };
+    auto do_3a = [&]() {
         // ---- 3a. M1-point DFTs over n1 for every (m, n2), then twiddle W_M^{n2 k1}; in place:
         //      slot M2 k1 + n2 of row m receives B[n2][k1]
 #ifndef SNOUT_ABL_NO3A
@@ -428,10 +406,9 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             }
         }
 #endif
-        STAMP(4);
-        lds_barrier();
-        STAMP(5);
-
+    };
+    auto do_3b = [&](uint32_t tile) {
+        const uint64_t m0 = (uint64_t)tile * T;
         // ---- 3b. M2-point DFTs over n2 for every (m pair, k1); y_k[m] = (-1)^{km} X[k].
         //      Fused: in place, channel k = k1 + M1 k2 ends up in slot M2 k1 + k2 of row m.
         //      Otherwise a thread owns two consecutive output times so each global store is 16 B.
@@ -619,6 +596,31 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
             }
         }
         // the next tile's FIR writes us only after the staging barrier, i.e. after every read above
+    };
+
+    for (uint32_t tile = t_first; tile < t_last; tile++) {
+        do_stage();
+        STAMP(0);
+        lds_barrier();
+        STAMP(1);
+        // The FIR is the throughput phase (128 independent packed FMAs per thread); the FFT passes and
+        // the slicer are dependency chains with LDS round trips in them, and the workgroup waits for
+        // their slowest wave at every barrier.  The SIMD arbitrates by priority, then age: with equal
+        // priority another workgroup's FIR waves take the issue slots the FFT waves need between their
+        // stalls.  FIR at priority 0, everything else at 1: -10 % on the whole kernel (tools/pfb_ab.py).
+        __builtin_amdgcn_s_setprio(SNOUT_PFB_PRIO_FIR);
+        do_prefetch(tile + 1u);
+        do_fir();
+        STAMP(2);
+        __builtin_amdgcn_s_setprio(SNOUT_PFB_PRIO_FFT);
+        lds_barrier();
+        STAMP(3);
+        do_3a();
+        STAMP(4);
+        lds_barrier();
+        STAMP(5);
+        do_3b(tile);
+        // the next tile's FIR writes us only after the staging barrier, i.e. after every read above
         STAMP(6);
     }
 #ifdef SNOUT_PFB_STAMPS
@@ -633,6 +635,23 @@ __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu(
         }
     }
 #endif
+}
+
+#define SNOUT_PFB_ARGS                                                                                   \
+    const void* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,      \
+    const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,        \
+    float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16, uint64_t plane_stride, PfbZbOut zb
+// Register budgets: M = 40 needs 4 wave slots per SIMD (<= 128 VGPRs) or a second 5-wave workgroup does not fit
+// a CU next to the first; the fused 802.15.4 epilogue is built for 3 (148 VGPRs, nothing spilled).
+// NB the backend also RAISES next_free_vgpr to match an occupancy it derives from static LDS: a variant of this
+// kernel with > 54.6 KB of static LDS (= fewer than three workgroups per CU by LDS) got next_free_vgpr 129 for
+// 114 used registers, hence 3 wave slots per SIMD and ONE resident workgroup (tools/occprobe.hip,
+// profiles/r2_pfb_experiments.md).
+template <int M, bool FUSED, int FMT>
+__global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu((FUSED && M == 16) ? SNOUT_PFB_WPE_ZB : SNOUT_PFB_WPE)))
+void pfb_channelize(SNOUT_PFB_ARGS)
+{
+    pfb_body<M, FUSED, FMT>(x, n, n_out, n_tiles, tiles_per_wg, proto, twM, tw5g, y, y_stride, planes16, plane_stride, zb);
 }
 
 // =============================================================================================
@@ -722,7 +741,12 @@ int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16
             const uint64_t done = (uint64_t)n_tiles * PfbGeom<16>::T;
             if (done < zbt->d_stride)
                 SNOUT_HIP(hipMemset2DAsync(zbt->d + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
-            SNOUT_PFB(16, true, (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0);
+#define SNOUT_PFB_ZB(F) hipLaunchKernelGGL((pfb_channelize<16, true, F>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st, d_iq, n, n_out, \
+            n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0, zb)
+            if (fmt == kFmtSc8) SNOUT_PFB_ZB(kFmtSc8);
+            else if (fmt == kFmtSc16) SNOUT_PFB_ZB(kFmtSc16);
+            else SNOUT_PFB_ZB(kFmtCf32);
+#undef SNOUT_PFB_ZB
         } else {
             SNOUT_PFB(16, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
         }

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SNOUT_RX_LIB"] = os.path.join(ROOT, "build", "variants", "libsnout_rx_stamps.so")
+os.environ["SNOUT_RX_LIB"] = os.path.join(ROOT, "build", "variants", "libsnout_rx_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "stamps"))
 from snout_amd import synth, _ffi
 from snout_amd.rx import SnoutRx
 tile, _ = synth.wideband_capture(0, 40 * (1 << 16), seed=3, sigma=0.0)
@@ -40,3 +40,19 @@ key = tt[:, 2] * 1000 + se * 100 + sh * 16 + cu
 import collections
 cnt = collections.Counter(key[~late].tolist())
 print("early workgroups per (xcc, se, sh, cu): histogram of counts", collections.Counter(cnt.values()))
+# residency per CU: maximum number of overlapping workgroups, and how long workgroups run by CU load
+byk = collections.defaultdict(list)
+for i in range(768):
+    if tt[i, 1] > tt[i, 0]:
+        byk[int(key[i])].append(i)
+load = {}
+for k, idx in byk.items():
+    ev = sorted([(start[i], 1) for i in idx] + [(end[i], -1) for i in idx])
+    cur = best = 0
+    for _, d in ev:
+        cur += d; best = max(best, cur)
+    load[k] = best
+print("CUs seen %d; max overlapping workgroups per CU: histogram" % len(load), sorted(collections.Counter(load.values()).items()))
+for L in sorted(set(load.values())):
+    idx = [i for k, v in byk.items() if load[k] == L for i in v]
+    print("  CUs with %d resident: %d workgroups, run time median %.0f us, last end %.0f us" % (L, len(idx), np.median((end - start)[idx]), end[idx].max()))
