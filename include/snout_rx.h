@@ -86,7 +86,9 @@ typedef struct snout_rx_cfg {
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
     uint32_t flags;           /* SNOUT_CFG_* bits                                                */
     uint32_t sample_format;   /* SNOUT_FMT_* of every iq pointer handed to this handle (0 = cf32)  */
-    uint32_t reserved[2];     /* zero                                                            */
+    uint32_t batch_segments;  /* segments one snout_rx_submit_batch_dev call may carry; 0 -> 1.
+                                 > 1: wideband handles (n_channels > 1) only, at most 8           */
+    uint32_t reserved[1];     /* zero                                                            */
 } snout_rx_cfg;
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
@@ -147,6 +149,20 @@ int  snout_rx_process_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
  * kernels of segment i+1.  iq_dev must stay valid and unchanged until its collect returns. */
 int  snout_rx_submit_dev  (snout_rx* h, const void* iq_dev, uint64_t n_samples,
                            uint64_t first_sample_index, void* hip_stream);
+/* Several capture segments of EQUAL length as one submission (handle created with cfg.batch_segments
+ * >= count): short segments leave most of the GPU idle inside the lane-serial 802.15.4 kernels (a 2^24-
+ * sample wideband segment is 256 waves of clock recovery on 256 CUs), a batch runs them side by side.
+ * The records of the batch come out of ONE collect, ordered by (segment, channel, sample_index), each
+ * with its own segment's first_sample_index[k] added; records whose sample_index is below
+ * min_sample_index[k] are dropped (NULL: none) -- a sharded scan leaves what a segment finds in its
+ * pre-roll to the segment before it (replaces `snout/core/radio.py:415`'s one-channel-at-a-time loop
+ * together with snout_rx_submit_dev).  Same results as `count` single submissions. */
+int  snout_rx_submit_batch_dev(snout_rx* h, const void* const* iq_devs, uint32_t count, uint64_t n_samples,
+                               const uint64_t* first_sample_index, const uint64_t* min_sample_index,
+                               void* hip_stream);
+/* 1 if the oldest submitted segment has finished (its collect will not wait), 0 if not yet (or nothing
+ * is pending), negative on error: lets one host thread drive several handles without blocking on one. */
+int  snout_rx_poll        (snout_rx* h);
 int  snout_rx_collect     (snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out);
 int  snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out);
 /* Device copy of the records of the segment collected last (same lifetime as the collect_view

@@ -25,7 +25,7 @@ EXPORTS = [
     "snout_rx_profile_history", "snout_btle_format_line", "snout_rftap_encap",
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
     "snout_strerror", "snout_last_error", "snout_abi_version", "snout_hbm_read_gbps",
-    "snout_rx_pack_last_records",
+    "snout_rx_pack_last_records", "snout_rx_submit_batch_dev", "snout_rx_poll",
 ]
 
 
@@ -41,7 +41,7 @@ class RxCfg(C.Structure):
                 ("access_addr", C.c_uint32), ("crc_init", C.c_uint32),
                 ("chip_threshold", C.c_uint32), ("zb_core", C.c_uint32), ("zb_warmup", C.c_uint32),
                 ("max_hits", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("sample_format", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("sample_format", C.c_uint32), ("batch_segments", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class RxProf(C.Structure):
@@ -84,6 +84,10 @@ def load() -> C.CDLL:
     lib.snout_rx_process_dev.restype = C.c_int
     lib.snout_rx_submit_dev.argtypes = [vp, vp, u64, u64, vp]
     lib.snout_rx_submit_dev.restype = C.c_int
+    lib.snout_rx_submit_batch_dev.argtypes = [vp, C.POINTER(vp), C.c_uint32, u64, C.POINTER(u64), C.POINTER(u64), vp]
+    lib.snout_rx_submit_batch_dev.restype = C.c_int
+    lib.snout_rx_poll.argtypes = [vp]
+    lib.snout_rx_poll.restype = C.c_int
     lib.snout_rx_collect.argtypes = [vp, vp, u64, C.POINTER(u64)]
     lib.snout_rx_collect.restype = C.c_int
     lib.snout_rx_collect_view.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void btle_decode(
     const uint32_t* __restrict__ hit_n, const uint16_t* __restrict__ hit_slot,
     const uint32_t* __restrict__ totals, uint32_t max_cand,
     const uint64_t* __restrict__ whiten /* [n_slots][6] u64 words */,
-    const uint16_t* __restrict__ slot_channel, uint32_t crc_init, uint64_t first_index,
+    const uint16_t* __restrict__ slot_channel, uint32_t crc_init, SegBatch segs,
     BtleCand* __restrict__ cand, snout_pkt* __restrict__ stage)
 {
     __shared__ uint32_t crc_tab[256];      // reflected CRC24 table (poly 0x00065B reflected = 0xDA6000)
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void btle_decode(
                     }
                     snout_pkt* o = &stage[idx];
                     uint4* o4 = reinterpret_cast<uint4*>(o);
-                    const uint64_t si = first_index + (uint64_t)(n_hit - 124u);
+                    const uint64_t si = segs.first[slot / segs.slots_per_seg] + (uint64_t)(n_hit - 124u);
                     const uint32_t ok = (rx == crc) ? 1u : 0u;
                     const uint32_t fl = ((b0 >> 6) & 1u) | (((b0 >> 7) & 1u) << 1);
                     o4[0] = make_uint4((uint32_t)si, (uint32_t)(si >> 32), SNOUT_PROTO_BTLE,
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void btle_decode(
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void btle_resolve(const BtleCand* __restrict__ cand,
                                                     const uint32_t* __restrict__ totals,
-                                                    uint32_t max_cand,
+                                                    uint32_t max_cand, SegBatch segs,
                                                     uint32_t* __restrict__ accept_flag)
 {
     uint32_t n = totals[0];
@@ -531,10 +531,14 @@ __global__ __launch_bounds__(256) void btle_resolve(const BtleCand* __restrict__
         uint32_t k = i;
         BtleCand c = me;
         uint32_t last_n = me.n_hit;
+        // packets that start before the segment's min index were examined all the same (the search
+        // resumes behind them) but belong to the capture segment before this one: not reported
+        const uint32_t sg = me.slot / segs.slots_per_seg;
+        const uint64_t first = segs.first[sg], min_index = segs.min_index[sg];
         while (true) {
             uint32_t acc = 0;
             if ((uint64_t)c.n_hit >= resume + 124u) {      // examined by the sequential search
-                acc = c.status == 0 ? 1u : 0u;
+                acc = (c.status == 0 && first + (uint64_t)(c.n_hit - 124u) >= min_index) ? 1u : 0u;
                 resume = c.next;
             }
             accept_flag[k] = acc;
@@ -606,10 +610,12 @@ void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fi
                        tile_sums, tile_over);
 }
 
-int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_, uint32_t crc_init_,
-                  uint32_t max_hits_)
+int BtleCtx::init(uint32_t seg_slots_, const uint16_t* slot_channel_, uint32_t aa_, uint32_t crc_init_,
+                  uint32_t max_hits_, uint32_t batch_cap_)
 {
-    n_slots = n_slots_;
+    seg_slots = seg_slots_;
+    batch_cap = batch_cap_ ? batch_cap_ : 1u;
+    n_slots = seg_slots * batch_cap;                // tables for every slot of a full batch
     aa = aa_;
     crc_init = crc_init_;
     max_hits_cfg = max_hits_;
@@ -619,7 +625,7 @@ int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_
     std::vector<uint64_t> wh(6u * n_slots, 0ull);
     std::vector<uint16_t> ch(n_slots);
     for (uint32_t s = 0; s < n_slots; s++) {
-        ch[s] = slot_channel_[s];
+        ch[s] = slot_channel_[s % seg_slots];       // the slots of every segment of a batch carry the same channels
         uint32_t reg = 1u;                                  // bit i = position i
         for (int i = 0; i < 6; i++) reg |= ((ch[s] >> (5 - i)) & 1u) << (1 + i);
         for (int b = 0; b < 384; b++) {
@@ -633,6 +639,7 @@ int BtleCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t aa_
     if (int rc = d_slot_channel.ensure(ch.size() * 2)) return rc;
     SNOUT_HIP(hipMemcpy(d_whiten.p, wh.data(), wh.size() * 8, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_slot_channel.p, ch.data(), ch.size() * 2, hipMemcpyHostToDevice));
+    n_slots = seg_slots;                            // slots of the current call (reserve)
     return 0;
 }
 
@@ -644,8 +651,10 @@ void BtleCtx::destroy()
 }
 
 // Size every buffer for `n` channel-samples per slot.
-int BtleCtx::reserve(uint64_t n)
+int BtleCtx::reserve(uint64_t n, uint32_t segs)
 {
+    if (segs == 0 || segs > batch_cap) { set_last_error("batch of %u segments (handle created for %u)", segs, batch_cap); return SNOUT_EINVAL; }
+    n_slots = seg_slots * segs;                     // slot = (segment of the batch, channel)
     n_chunks = cdiv(n, kChunkSamples);
     plane_stride = (uint64_t)(n_chunks + 1) * kChunkIters * 4u;     // u64 words per slot (+1 chunk pad)
     const uint64_t lists = (uint64_t)n_chunks * n_slots;
@@ -710,8 +719,10 @@ int BtleCtx::launch_corr_planes(uint64_t n, hipStream_t st)
 // Hit lists -> resolved, ordered packet records in s.d_out; counts in s.d_totals.  No host sync.
 // totals (u32): [0] candidates  [1] packets  [2] chunks whose list overflowed
 //               [16 ..) list tile sums, [16+kMaxTiles ..) accept tile sums, [16+2 kMaxTiles ..) overflow
-int BtleCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s)
+int BtleCtx::enqueue_tail(uint64_t n, const SegBatch& segs_in, hipStream_t st, ResultSlot& s)
 {
+    SegBatch segs = segs_in;
+    segs.slots_per_seg = seg_slots;
     if (int rc = s.d_out.ensure((uint64_t)max_cand * sizeof(snout_pkt))) return rc;
     const uint32_t lists = n_chunks * n_slots;
     uint32_t* tot = s.d_totals.as<uint32_t>();
@@ -728,9 +739,9 @@ int BtleCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, Resu
     const uint32_t g = std::min<uint32_t>(cdiv(max_cand, 256), 1024u);
     hipLaunchKernelGGL(btle_decode, dim3(g), dim3(256), 0, st, d_planes.as<uint64_t>(), plane_stride,
                        n - 4u, d_hit_n.as<uint32_t>(), d_hit_slot.as<uint16_t>(), tot, max_cand,
-                       d_whiten.as<uint64_t>(), d_slot_channel.as<uint16_t>(), crc_init, first_index,
+                       d_whiten.as<uint64_t>(), d_slot_channel.as<uint16_t>(), crc_init, segs,
                        d_cand.as<BtleCand>(), d_stage.as<snout_pkt>());
-    hipLaunchKernelGGL(btle_resolve, dim3(g), dim3(256), 0, st, d_cand.as<BtleCand>(), tot, max_cand,
+    hipLaunchKernelGGL(btle_resolve, dim3(g), dim3(256), 0, st, d_cand.as<BtleCand>(), tot, max_cand, segs,
                        d_accept.as<uint32_t>());
     hipLaunchKernelGGL(tile_reduce, dim3(n_cand_tiles), dim3(256), 0, st, d_accept.as<uint32_t>(),
                        tot, 0u, max_cand, 1u, acc_tiles, (uint32_t*)nullptr);

@@ -59,6 +59,15 @@ struct DevBuf {
 
 // One in-flight result: device-side record buffer + totals, pinned host mirrors, events.
 // Two of them let the record D2H of segment i overlap the kernels of segment i+1.
+// A batch of capture segments of equal length handled as ONE call (snout_rx_submit_batch_dev): segment k
+// owns the channel slots [k slots_per_seg, (k + 1) slots_per_seg).  By value in kernel arguments.
+constexpr uint32_t kMaxBatch = 8;
+struct SegBatch {
+    uint64_t first[kMaxBatch];          // channel-sample index of the segment's first sample
+    uint64_t min_index[kMaxBatch];      // records that start before it are dropped (0: keep all)
+    uint32_t slots_per_seg, count;
+};
+
 struct ResultSlot {
     DevBuf d_out, d_totals;              // records; totals: [0] candidates/lanes [1] packets [2] overflow
     uint32_t* h_totals = nullptr;        // pinned, 16 u32
@@ -68,6 +77,8 @@ struct ResultSlot {
                ev_compute = nullptr, ev_copy = nullptr;
     // bookkeeping of the submitted segment
     const void* iq = nullptr;           // cf32 / sc8 / sc16 as the handle is configured (iq_fmt.h)
+    const void* iq_more[kMaxBatch] = {};   // segments 1.. of a batch (iq is segment 0)
+    SegBatch segs = {};
     uint64_t n_in = 0, first_index = 0, spec_copied = 0, n_pkts = 0;
     hipStream_t stream = nullptr;
     bool timed = false;
@@ -80,7 +91,8 @@ struct ResultSlot {
 
 // BTLE pipeline state shared by the narrowband and the channelized front ends (btle.hip).
 struct BtleCtx {
-    uint32_t n_slots = 0, aa = 0, crc_init = 0, max_hits_cfg = 0, max_cand_grown = 0;
+    uint32_t n_slots = 0, aa = 0, crc_init = 0, max_hits_cfg = 0, max_cand_grown = 0;     // n_slots: slots of the current call
+    uint32_t seg_slots = 0, batch_cap = 1;          // slots per segment; segments a call may hold
     uint32_t n_chunks = 0, max_cand = 0, last_n_cand = 0;
     uint32_t hit_cap = 64;          // candidate hits one 16384-sample chunk can hold (grows on overflow)
     bool overflow_chunk = false, overflow_cand = false;
@@ -89,15 +101,15 @@ struct BtleCtx {
     DevBuf d_planes, d_chunk_cnt, d_chunk_hits, d_hit_n, d_hit_slot, d_cand, d_stage, d_accept,
         d_whiten, d_slot_channel;
 
-    int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t aa, uint32_t crc_init,
-             uint32_t max_hits);
+    int init(uint32_t seg_slots, const uint16_t* slot_channel, uint32_t aa, uint32_t crc_init,
+             uint32_t max_hits, uint32_t batch_cap = 1);
     void destroy();
-    int reserve(uint64_t n_channel_samples);
+    int reserve(uint64_t n_channel_samples, uint32_t segs = 1);
     int launch_demod_corr(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
                           ResultSlot* timing, int fmt = 0);
     int launch_corr_planes(uint64_t n, hipStream_t st);
     // hit lists -> ordered records in s.d_out, totals in s.d_totals (no host sync)
-    int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s);
+    int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s);
     // inspect the totals of a finished slot; true if capacity was exceeded (and grows it)
     bool check_overflow(const ResultSlot& s);
 };
@@ -138,7 +150,8 @@ struct PfbCtx {
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).
 struct ZbCtx {
-    uint32_t n_slots = 0, threshold = 10, core = 2048, warmup = 512;
+    uint32_t n_slots = 0, threshold = 10, core = 2048, warmup = 512;      // n_slots: slots of the current call
+    uint32_t seg_slots = 0, batch_cap = 1;                                 // slots per segment; segments a call may hold
     uint32_t lanes_per_slot = 0, total_lanes = 0, max_out = 0;
     uint32_t pkts_per_lane = 8;     // record slots per lane (grows on overflow)
     uint32_t n_waves = 0, nt = 0, tiles_per_slot = 0;   // waves of 64 lanes, 64-sample tiles per lane
@@ -154,17 +167,17 @@ struct ZbCtx {
     uint64_t nsb = 0;
 
     int init(uint32_t n_slots, const uint16_t* slot_channel, uint32_t threshold, uint32_t core,
-             uint32_t warmup);
+             uint32_t warmup, uint32_t batch_cap = 1);
     void destroy();
-    int reserve(uint64_t n_channel_samples);
-    int launch_sinks(uint64_t first_index, hipStream_t st);
+    int reserve(uint64_t n_channel_samples, uint32_t segs = 1);
+    int launch_sinks(const SegBatch& segs, hipStream_t st);
     // front end (discriminator, carry-in, lanes) and tail (stitch, sinks, ordered compaction into
     // s.d_out / s.d_totals); no host sync
     // d_iq == nullptr: the fused channelizer has already written d and S (see pfb_target)
     int enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
                       bool time_front, int fmt = 0);
-    PfbZbTarget pfb_target() const;
-    int enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s, bool time_front);
+    PfbZbTarget pfb_target(uint32_t seg = 0) const;
+    int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s, bool time_front);
     bool check_overflow(const ResultSlot& s);
     int soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out);
 };

@@ -166,16 +166,26 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     if (h->wide) {
         n_ch = h->pfb.n_out_for(s.n_in);
         BtleCtx& bw = btle_of(h, s);
-        if (fused) { if (int rc = bw.reserve(n_ch)) return rc; }
+        if (fused) { if (int rc = bw.reserve(n_ch, s.segs.count)) return rc; }
         PfbZbTarget zt{};
         if (fused_zb) {
             ZbCtx& z = zb_of(h, s);
-            if (int rc = z.reserve(n_ch)) return rc;
+            if (int rc = z.reserve(n_ch, s.segs.count)) return rc;
             zt = z.pfb_target();
         }
         SNOUT_HIP(hipEventRecord(s.ev_k0, st));
         if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
                                 bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr, ch_fmt)) return rc;
+        // the other segments of a batch: the same channelizer launch into their own rows of the context
+        for (uint32_t k = 1; k < s.segs.count; k++) {
+            if (fused) {
+                uint16_t* planes_k = bw.d_planes.as<uint16_t>() + (uint64_t)k * bw.seg_slots * bw.plane_stride * 4u;
+                if (int rc = h->pfb.run(s.iq_more[k], s.n_in, st, planes_k, bw.plane_stride, nullptr, ch_fmt)) return rc;
+            } else {
+                zt = zb_of(h, s).pfb_target(k);
+                if (int rc = h->pfb.run(s.iq_more[k], s.n_in, st, nullptr, 0, &zt, ch_fmt)) return rc;
+            }
+        }
         ch_fmt = 0;
         SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         ch_iq = (fused_zb && n_ch >= 9u) ? nullptr : h->pfb.d_y.as<float>();
@@ -183,7 +193,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     }
     if (h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = btle_of(h, s);
-        if (int rc = b.reserve(n_ch)) return rc;
+        if (int rc = b.reserve(n_ch, s.segs.count)) return rc;
         if (fused) {
             if (int rc = b.launch_corr_planes(n_ch, st)) return rc;       // bits are already in the planes
         } else {
@@ -191,17 +201,17 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         }
         if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, nb_btle ? s.ev_k1 : s.ev_front, 0));
-        if (int rc = b.enqueue_tail(n_ch, s.first_index, tail, s)) return rc;
+        if (int rc = b.enqueue_tail(n_ch, s.segs, tail, s)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
         return 0;
     } else {
         ZbCtx& z = zb_of(h, s);
-        if (int rc = z.reserve(n_ch)) return rc;
+        if (int rc = z.reserve(n_ch, s.segs.count)) return rc;
         if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
-        if (int rc = z.enqueue_tail(n_ch, s.first_index, tail, s, !h->wide)) return rc;
+        if (int rc = z.enqueue_tail(n_ch, s.segs, tail, s, !h->wide)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
         return 0;
@@ -312,7 +322,13 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     if (c.zb_core == 0) c.zb_core = 2048;
     if (c.zb_warmup == 0) c.zb_warmup = 512;
     if (c.n_channels == 0) c.n_channels = 1;
+    if (c.batch_segments == 0) c.batch_segments = 1;
     int rc = SNOUT_EINVAL;
+    if (c.batch_segments > kMaxBatch || (c.batch_segments > 1 && (c.n_channels == 1 || (c.flags & SNOUT_CFG_KEEP_CHANNEL_IQ)))) {
+        set_last_error("batch_segments %u: 1..%u, wideband handles without SNOUT_CFG_KEEP_CHANNEL_IQ only",
+                       c.batch_segments, kMaxBatch);
+        goto fail;
+    }
     if (c.sample_format > SNOUT_FMT_SC16) { set_last_error("sample format %u", c.sample_format); goto fail; }
     if (c.proto == SNOUT_PROTO_ZIGBEE &&
         (c.zb_core < 1024 || c.zb_core > (1u << 24) || c.zb_warmup > (1u << 20))) {
@@ -344,11 +360,11 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (c.taps_per_branch != 16) { set_last_error("taps_per_branch must be 16"); goto fail; }
         rc = h->pfb.init(M);
         if (rc) goto fail;
-        rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits)
-                                         : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
-        if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle2.init(M, chs, c.access_addr, c.crc_init, c.max_hits);
-        if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle3.init(M, chs, c.access_addr, c.crc_init, c.max_hits);
-        if (!rc && c.proto == SNOUT_PROTO_ZIGBEE) rc = h->zb2.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup);
+        rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments)
+                                         : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
+        if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle2.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments);
+        if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle3.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments);
+        if (!rc && c.proto == SNOUT_PROTO_ZIGBEE) rc = h->zb2.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
         if (rc) goto fail;
     } else {
         set_last_error("configuration proto=%u n_channels=%u not supported (BTLE: 1 or 40, "
@@ -429,7 +445,22 @@ static bool too_short(snout_rx* h, uint64_t n_samples)
 int snout_rx_submit_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
                         uint64_t first_sample_index, void* hip_stream)
 {
-    if (int rc = check_segment(h, iq_dev, n_samples)) return rc;
+    return snout_rx_submit_batch_dev(h, &iq_dev, 1, n_samples, &first_sample_index, nullptr, hip_stream);
+}
+
+int snout_rx_submit_batch_dev(snout_rx* h, const void* const* iq_devs, uint32_t count, uint64_t n_samples,
+                              const uint64_t* first_sample_index, const uint64_t* min_sample_index,
+                              void* hip_stream)
+{
+    if (!h || !iq_devs || !first_sample_index || count == 0) return SNOUT_EINVAL;
+    if (count > h->cfg.batch_segments) {
+        set_last_error("batch of %u segments: the handle was created with batch_segments = %u", count, h->cfg.batch_segments);
+        return SNOUT_EINVAL;
+    }
+    for (uint32_t k = 0; k < count; k++)
+        if (int rc = check_segment(h, iq_devs[k], n_samples)) return rc;
+    const void* iq_dev = iq_devs[0];
+    const uint64_t first0 = first_sample_index[0];
     if (h->pending >= snout_rx::kSlots) {
         set_last_error("%d segments in flight: collect one first", snout_rx::kSlots);
         return SNOUT_EINVAL;
@@ -439,7 +470,14 @@ int snout_rx_submit_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
     s.work_set = (int)(h->n_submitted++ % (h->cfg.proto == SNOUT_PROTO_BTLE ? 3u : 2u));
     s.iq = iq_dev;
     s.n_in = n_samples;
-    s.first_index = first_sample_index;
+    s.first_index = first0;
+    s.segs = SegBatch{};
+    s.segs.count = count;
+    for (uint32_t k = 0; k < count; k++) {
+        s.iq_more[k] = iq_devs[k];
+        s.segs.first[k] = first_sample_index[k];
+        s.segs.min_index[k] = min_sample_index ? min_sample_index[k] : 0u;
+    }
     s.stream = (hipStream_t)hip_stream;
     s.n_pkts = 0;
     s.timed = false;
@@ -475,6 +513,17 @@ int snout_rx_submit_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
     }
     h->pending++;
     return SNOUT_OK;
+}
+
+int snout_rx_poll(snout_rx* h)
+{
+    if (!h) return SNOUT_EINVAL;
+    if (h->pending == 0) return 0;
+    const hipError_t e = hipEventQuery(h->slots[h->head].ev_copy);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    set_last_error("hipEventQuery: %s", hipGetErrorString(e));
+    return SNOUT_EHIP;
 }
 
 int snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out)

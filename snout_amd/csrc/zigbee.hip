@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void zb_walk(
     const uint32_t* __restrict__ first_owned, const uint32_t* __restrict__ slot_total,
     const uint32_t* __restrict__ TR, uint32_t nt, uint32_t lanes_per_slot, uint32_t total_lanes,
     uint32_t core, uint32_t warmup, uint32_t th, const uint16_t* __restrict__ slot_channel,
-    uint64_t first_index, snout_pkt* __restrict__ stage, uint32_t K, uint32_t* __restrict__ lane_cnt)
+    SegBatch segs, snout_pkt* __restrict__ stage, uint32_t K, uint32_t* __restrict__ lane_cnt)
 {
     // a few latency-bound waves that run beside the next segment's front end: issue them first
     __builtin_amdgcn_s_setprio(3);
@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256) void zb_walk(
     const bool exists = g < total_lanes;            // lanes past the end still help their wave decode
     const uint32_t gs = exists ? g : 0u;
     const uint32_t slot = gs / lanes_per_slot, li = gs % lanes_per_slot;
+    const uint64_t first_index = segs.first[slot / segs.slots_per_seg];     // the slot's segment of a batch
     const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
     const unsigned long long* mt = match + (uint64_t)slot * stream_words;
     const uint32_t total = exists ? slot_total[slot] : 0u;
@@ -924,10 +925,14 @@ constexpr int kResolveSet = 48;
 
 __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage, const uint32_t* __restrict__ lane_cnt,
                                                   uint32_t K, uint32_t lanes_per_slot, uint32_t total_lanes,
-                                                  const uint32_t* __restrict__ offs, uint32_t* __restrict__ lane_kept)
+                                                  const uint32_t* __restrict__ offs, SegBatch segs,
+                                                  uint32_t* __restrict__ lane_kept)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= total_lanes) return;
+    // records that start before this index belong to the capture segment before this one (sharded
+    // scans: the overlap / pre-roll of a segment); the sink was busy with them all the same
+    const uint64_t min_index = segs.min_index[g / lanes_per_slot / segs.slots_per_seg];
     const uint32_t raw = lane_cnt[g];
     if (raw > K) { lane_kept[g] = raw; return; }          // overflow: the segment is run again with more slots
     const uint32_t g_first = g - g % lanes_per_slot;        // first lane of this channel
@@ -967,6 +972,7 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
             if (!drop) { have = true; busy = endc[k]; }
             if (k == 0) keep_me = !drop;
         }
+        if (stage[(size_t)g * K + i].sample_index < min_index) keep_me = false;
         stage[(size_t)g * K + i].pdu_type = keep_me ? 0 : 1;
         kept += keep_me ? 1u : 0u;
     }
@@ -1052,9 +1058,10 @@ __global__ __launch_bounds__(256) void zb_emit(const snout_pkt* __restrict__ sta
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t threshold_, uint32_t core_,
-                uint32_t warmup_)
+                uint32_t warmup_, uint32_t batch_cap_)
 {
-    n_slots = n_slots_;
+    seg_slots = n_slots = n_slots_;
+    batch_cap = batch_cap_ ? batch_cap_ : 1u;
     threshold = threshold_;
     core = core_;
     warmup = warmup_;
@@ -1079,10 +1086,11 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
     }
     if (int rc = d_atan.ensure(257 * 4)) return rc;
     if (int rc = d_mmse.ensure(129 * 8 * 4)) return rc;
-    if (int rc = d_slot_channel.ensure(n_slots * 2)) return rc;
+    if (int rc = d_slot_channel.ensure((size_t)seg_slots * batch_cap * 2)) return rc;
     SNOUT_HIP(hipMemcpy(d_atan.p, atan_tab.data(), 257 * 4, hipMemcpyHostToDevice));
     SNOUT_HIP(hipMemcpy(d_mmse.p, kMmseTapsHost, 129 * 8 * 4, hipMemcpyHostToDevice));
-    SNOUT_HIP(hipMemcpy(d_slot_channel.p, slot_channel_, n_slots * 2, hipMemcpyHostToDevice));
+    for (uint32_t b = 0; b < batch_cap; b++)      // the slots of every segment of a batch carry the same channels
+        SNOUT_HIP(hipMemcpy(d_slot_channel.as<uint16_t>() + (size_t)b * seg_slots, slot_channel_, seg_slots * 2, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1094,8 +1102,10 @@ void ZbCtx::destroy()
     d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
 }
 
-int ZbCtx::reserve(uint64_t n)
+int ZbCtx::reserve(uint64_t n, uint32_t segs)
 {
+    if (segs == 0 || segs > batch_cap) { set_last_error("batch of %u segments (handle created for %u)", segs, batch_cap); return SNOUT_EINVAL; }
+    n_slots = seg_slots * segs;                     // slot = (segment of the batch, channel)
     lanes_per_slot = cdiv(n, core);
     total_lanes = lanes_per_slot * n_slots;
     n_waves = cdiv(total_lanes, 64);
@@ -1139,7 +1149,7 @@ __global__ __launch_bounds__(256) void zb_clear(ulonglong2* __restrict__ p, uint
 }
 
 // a7 and the glue before it: stitched chip streams -> sinks -> per-lane records (after zb_mm).
-int ZbCtx::launch_sinks(uint64_t first_index, hipStream_t st)
+int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
 {
     uint32_t* first_owned = d_lane_u32.as<uint32_t>();
     uint32_t* owned = first_owned + total_lanes;
@@ -1166,7 +1176,7 @@ int ZbCtx::launch_sinks(uint64_t first_index, hipStream_t st)
                        d_stream.as<unsigned long long>(), d_stream.as<unsigned long long>() + stream_words * n_slots,
                        stream_words, offs, first_owned, slot_total,
                        d_TR.as<uint32_t>(), nt, lanes_per_slot, total_lanes, core, warmup, threshold,
-                       d_slot_channel.as<uint16_t>(), first_index, d_stage.as<snout_pkt>(), pkts_per_lane,
+                       d_slot_channel.as<uint16_t>(), segs, d_stage.as<snout_pkt>(), pkts_per_lane,
                        d_lane_cnt.as<uint32_t>());
     SNOUT_HIP(hipGetLastError());
     return 0;
@@ -1248,15 +1258,16 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
     return 0;
 }
 
-PfbZbTarget ZbCtx::pfb_target() const
+PfbZbTarget ZbCtx::pfb_target(uint32_t seg) const
 {
-    return PfbZbTarget{d_d.as<float>(), d_stride, d_S.as<double>(), nsb, d_atan.as<float>(), d_iirw.as<double>()};
+    return PfbZbTarget{d_d.as<float>() + (uint64_t)seg * seg_slots * d_stride, d_stride,
+                       d_S.as<double>() + (uint64_t)seg * seg_slots * nsb, nsb, d_atan.as<float>(), d_iirw.as<double>()};
 }
 
 // Tail (stitch, a7, ordered compaction into s.d_out / s.d_totals) on the handle's tail stream, so
 // that it overlaps the next segment's front end (which uses the other work set).  No host sync.
 // totals (u32): [0] lanes  [1] packets  [2] lanes that held more than pkts_per_lane frames
-int ZbCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, ResultSlot& s, bool time_front)
+int ZbCtx::enqueue_tail(uint64_t n, const SegBatch& segs_in, hipStream_t st, ResultSlot& s, bool time_front)
 {
     if (int rc = s.d_out.ensure((uint64_t)max_out * sizeof(snout_pkt))) return rc;
     uint32_t* tot = s.d_totals.as<uint32_t>();
@@ -1267,12 +1278,14 @@ int ZbCtx::enqueue_tail(uint64_t n, uint64_t first_index, hipStream_t st, Result
         if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         return 0;
     }
-    if (int rc = launch_sinks(first_index, st)) return rc;
+    SegBatch segs = segs_in;
+    segs.slots_per_seg = seg_slots;
+    if (int rc = launch_sinks(segs, st)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
     uint32_t* lane_kept = d_lane_cnt.as<uint32_t>() + total_lanes + 1024u;
     hipLaunchKernelGGL(zb_resolve, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_stage.as<snout_pkt>(),
-                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, lanes_per_slot, total_lanes, d_lane_u32.as<uint32_t>() + 2u * (uint64_t)total_lanes, lane_kept);
+                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, lanes_per_slot, total_lanes, d_lane_u32.as<uint32_t>() + 2u * (uint64_t)total_lanes, segs, lane_kept);
     launch_tile_reduce(lane_kept, nullptr, total_lanes, total_lanes, pkts_per_lane,
                        sums, over, n_tiles, st);
     hipLaunchKernelGGL(zb_emit, dim3(n_tiles), dim3(256), 0, st, d_stage.as<snout_pkt>(),

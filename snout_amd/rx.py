@@ -34,7 +34,7 @@ class SnoutRx:
                  access_addr: int = 0, crc_init: int = 0, chip_threshold: int = 0,
                  taps_per_branch: int = 0, zb_core: int = 0, zb_warmup: int = 0,
                  max_hits: int = 0, device: int = -1, keep_channel_iq: bool = False,
-                 sample_format: int = 0):
+                 sample_format: int = 0, batch_segments: int = 1):
         self._lib = _ffi.load()
         cfg = _ffi.RxCfg(abi_version=_ffi.ABI_VERSION, proto=proto, n_channels=n_channels,
                          taps_per_branch=taps_per_branch, channel=channel,
@@ -43,6 +43,8 @@ class SnoutRx:
                          max_hits=max_hits, device=device)
         cfg.flags = 1 if keep_channel_iq else 0            # SNOUT_CFG_KEEP_CHANNEL_IQ: unfused wideband kernels (CHAN_IQ tap)
         cfg.sample_format = int(sample_format)             # FMT_CF32 / FMT_SC8 / FMT_SC16
+        cfg.batch_segments = int(batch_segments)           # segments one submit_batch() may carry
+        self.batch_segments = max(1, int(batch_segments))
         self.sample_format = int(sample_format)
         self._h = C.c_void_p()
         _ffi.check(self._lib.snout_rx_create(C.byref(cfg), C.byref(self._h)))
@@ -139,6 +141,36 @@ class SnoutRx:
         st = stream if stream is not None else torch.cuda.current_stream(iq.device).cuda_stream
         _ffi.check(self._lib.snout_rx_submit_dev(self._h, C.c_void_p(iq.data_ptr()), n,
                                                  first_sample_index, C.c_void_p(st)))
+
+    def submit_batch(self, iqs, first_sample_indices, min_sample_indices=None, stream: Optional[int] = None) -> None:
+        """Enqueue several device-resident segments of EQUAL length as one submission (handle created
+        with ``batch_segments`` >= len(iqs)); one :meth:`collect` returns the records of all of them,
+        ordered by (segment, channel, sample_index).  ``min_sample_indices[k]``: records of segment k
+        that start before it are dropped on the device."""
+        import torch
+        n = None
+        for iq in iqs:
+            if not (isinstance(iq, torch.Tensor) and iq.is_cuda and iq.is_contiguous()):
+                raise TypeError("submit_batch() needs contiguous torch CUDA tensors")
+            m = self._tensor_samples(iq)
+            if n is not None and m != n:
+                raise ValueError("the segments of a batch must have equal lengths")
+            n = m
+        k = len(iqs)
+        if k == 0 or len(first_sample_indices) != k or (min_sample_indices is not None and len(min_sample_indices) != k):
+            raise ValueError("one first_sample_index (and min_sample_index) per segment")
+        st = stream if stream is not None else torch.cuda.current_stream(iqs[0].device).cuda_stream
+        ptrs = (C.c_void_p * k)(*[iq.data_ptr() for iq in iqs])
+        firsts = (C.c_uint64 * k)(*[int(v) for v in first_sample_indices])
+        mins = (C.c_uint64 * k)(*[int(v) for v in min_sample_indices]) if min_sample_indices is not None else None
+        _ffi.check(self._lib.snout_rx_submit_batch_dev(self._h, ptrs, k, n, firsts, mins, C.c_void_p(st)))
+
+    def ready(self) -> bool:
+        """True if the oldest submitted segment has finished: :meth:`collect` will not wait."""
+        rc = self._lib.snout_rx_poll(self._h)
+        if rc < 0:
+            _ffi.check(rc)
+        return rc == 1
 
     def collect(self, copy: bool = True) -> np.ndarray:
         """Records of the oldest submitted segment. ``copy=False``: a view of the handle's pinned

@@ -29,10 +29,12 @@ class ShardedScan:
     """``handles`` > 1 keeps that many receiver handles, each on its own stream, and deals the
     segments to them in turn: short segments leave most of the GPU idle inside the latency-bound
     kernels (a 2^24-sample Zigbee segment is 128 waves of clock recovery), and independent handles
-    let consecutive segments overlap."""
+    let consecutive segments overlap.  ``batch`` > 1 (wideband 802.15.4) hands that many segments of
+    equal length to the library as ONE submission (``snout_rx_submit_batch_dev``): they run side by
+    side inside the same kernels instead of one behind the other."""
 
     def __init__(self, proto: int, n_channels: int = 1, channel: int = 37, seg_len: int = 1 << 24,
-                 device: int = -1, handles: int = 1, **rx_kw):
+                 device: int = -1, handles: int = 1, batch: int = 1, **rx_kw):
         self.proto = proto
         self.n_channels = n_channels
         self.decim = n_channels // 2 if n_channels > 1 else 1
@@ -43,6 +45,9 @@ class ShardedScan:
         self.seg_len = max(step, seg_len // step * step)
         pre = 0 if proto == PROTO_BTLE else ZIGBEE_PREROLL_CH * self.decim
         self.preroll = (pre + step - 1) // step * step                # in input samples
+        self.batch = max(1, int(batch))
+        if self.batch > 1:
+            rx_kw = dict(rx_kw, batch_segments=self.batch)
         self.rxs = [SnoutRx(proto=proto, channel=channel, n_channels=n_channels, device=device, **rx_kw)
                     for _ in range(max(1, handles))]
         self.rx = self.rxs[0]
@@ -81,35 +86,56 @@ class ShardedScan:
         self._source = source
         self._sink = sink
         self._appended = [None] * len(self.rxs)     # event behind the last device-side append of each handle
-        self._next = 0                  # next segment to submit
-        self._done = 0                  # segments collected
-        self._alive = {}                # segment index -> tensor (kept until collected)
+        # submissions: runs of up to `batch` consecutive segments of equal length
+        self._subs = []
+        for j, (a, b) in enumerate(self._segs):
+            if self._subs and len(self._subs[-1]) < self.batch and (b - a) == (self._segs[self._subs[-1][0]][1] - self._segs[self._subs[-1][0]][0]):
+                self._subs[-1].append(j)
+            else:
+                self._subs.append([j])
+        self._next = 0                  # next submission
+        self._done = 0                  # submissions collected
+        self._alive = {}                # submission index -> tensors (kept until collected)
         self._parts = []
 
     def active(self) -> bool:
-        return self._done < len(self._segs)
+        return self._done < len(self._subs)
 
-    def step(self) -> None:
-        """Submit the next segment if a slot is free (two per handle), else collect the oldest."""
+    def step(self, block: bool = True) -> bool:
+        """Submit the next segment if a slot is free (two per handle), else collect the oldest.
+        ``block=False``: collect only if it has finished; returns False if nothing could be done."""
         import torch
         H = len(self.rxs)
-        if self._next < len(self._segs) and self._next - self._done < 2 * H:
+        if (not block and self._done < self._next and self._next - self._done >= H
+                and self.rxs[self._done % H].ready()):
+            pass                                    # results are waiting: take them before queueing more
+        elif self._next < len(self._subs) and self._next - self._done < 2 * H:
             j = self._next
-            a, b = self._segs[j]
+            sub = self._subs[j]
             st = self._streams[j % H]
             if self._appended[j % H] is not None:
                 # the result slot this submit reuses may still be being read by the sink's copy
                 st.wait_event(self._appended[j % H])
                 self._appended[j % H] = None
             with torch.cuda.stream(st):
-                x = self._source(a, b)
-                self.rxs[j % H].submit(x, first_sample_index=a // self.decim, stream=st.cuda_stream)
-            self._alive[j] = x
+                xs = [self._source(*self._segs[i]) for i in sub]
+                if self.batch > 1:
+                    # the library drops what a segment finds before its own range (its pre-roll)
+                    self.rxs[j % H].submit_batch(xs, [self._segs[i][0] // self.decim for i in sub],
+                                                 [self._own_from[i] if self.preroll else 0 for i in sub],
+                                                 stream=st.cuda_stream)
+                else:
+                    self.rxs[j % H].submit(xs[0], first_sample_index=self._segs[sub[0]][0] // self.decim,
+                                           stream=st.cuda_stream)
+            self._alive[j] = xs
             self._next += 1
-        elif self._done < self._next:
+            return True
+        if self._done < self._next:
             j = self._done
             rx = self.rxs[j % H]
-            own = self._own_from[j] if self.preroll else 0
+            if not block and not rx.ready():
+                return False
+            own = self._own_from[self._subs[j][0]] if (self.preroll and self.batch == 1) else 0
             if self._sink is not None:
                 rec = rx.collect(copy=False)                    # segments of a handle complete in order
                 self._sink.append(rec, own_from=own, rx=rx)
@@ -124,6 +150,8 @@ class ShardedScan:
                 self._parts.append(rec)
             del self._alive[j]
             self._done += 1
+            return True
+        return False
 
     def finish(self, parts, group=None, gather_device=None) -> Optional[np.ndarray]:
         """Gather this rank's records on rank 0 and drop the duplicates of the overlaps."""
@@ -152,11 +180,15 @@ class ShardedScan:
 
 
 def pump(scans) -> None:
-    """Drive started scans to completion, taking turns (see run_concurrent)."""
-    while any(sc.active() for sc in scans):
-        for sc in scans:
-            if sc.active():
-                sc.step()
+    """Drive started scans to completion from one host thread: every scan submits while it has a free
+    slot and collects what has finished; the thread waits (in one scan's collect) only when no scan can
+    do either -- a blocking collect per turn kept the other scan's queue from being refilled."""
+    while True:
+        live = [sc for sc in scans if sc.active()]
+        if not live:
+            return
+        if not any([sc.step(block=False) for sc in live]):
+            live[0].step()
 
 
 def run_concurrent(scans, n_totals, sources, group=None, gather_device=None, stats: Optional[dict] = None):
@@ -168,10 +200,7 @@ def run_concurrent(scans, n_totals, sources, group=None, gather_device=None, sta
     t0 = time.perf_counter()
     for sc, n, src in zip(scans, n_totals, sources):
         sc.start(n, src, group)
-    while any(sc.active() for sc in scans):
-        for sc in scans:
-            if sc.active():
-                sc.step()
+    pump(scans)
     t1 = time.perf_counter()
     out = [sc.finish(sc._parts, group, gather_device) for sc in scans]
     if stats is not None:
