@@ -146,6 +146,10 @@ struct PfbCtx {
     // zbt != null (M = 16): fused 802.15.4 mode, discriminator output goes straight to the Zigbee context
     int run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16 = nullptr,
             uint64_t plane_stride = 0, const PfbZbTarget* zbt = nullptr, int fmt = 0);
+    // several equal-length segments in one launch (fused modes only), outputs k "seg" strides apart
+    int run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStream_t st, uint16_t* planes16,
+                  uint64_t plane_stride, uint64_t planes_seg, const PfbZbTarget* zbt, uint64_t d_seg,
+                  uint64_t S_seg, int fmt);
 };
 
 // Zigbee / IEEE 802.15.4 pipeline state (zigbee.hip).

@@ -149,6 +149,15 @@ struct PfbZbOut {
     const double* iir_w;
 };
 
+// The segments of one launch (a batch of equal-length capture segments, snout_rx_submit_batch_dev): the
+// grid is `wgs_per_seg` workgroups per segment; segment k reads x[k] and writes k "seg" strides further.
+struct PfbSegs {
+    const void* x[kMaxBatch];
+    uint32_t wgs_per_seg;
+    uint64_t planes_seg;        // uint16 elements between the bit planes of consecutive segments
+    uint64_t d_seg, S_seg;      // floats / doubles between their discriminator rows / sub-block sums
+};
+
 template <int M> struct PfbGeom;
 template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320; };
 template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256; };
@@ -173,11 +182,17 @@ template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, N
 // FMT: input sample format (iq_fmt.h); integer samples are converted as they are fetched.
 template <int M, bool FUSED, int FMT>
 __device__ __forceinline__ void pfb_body(
-    const void* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
+    const PfbSegs& segs, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16,
     uint64_t plane_stride, PfbZbOut zb)
 {
+    // which segment of the launch this workgroup works on, and which of that segment's workgroups it is
+    const uint32_t seg = blockIdx.x / segs.wgs_per_seg, bid = blockIdx.x - seg * segs.wgs_per_seg;
+    const void* __restrict__ x = segs.x[seg];
+    if (planes16) planes16 += (uint64_t)seg * segs.planes_seg;
+    zb.d += (uint64_t)seg * segs.d_seg;
+    zb.S += (uint64_t)seg * segs.S_seg;
     using G = PfbGeom<M>;
     constexpr int T = G::T, M1 = G::M1, M2 = G::M2, D = M / 2, P = 16, NT = G::NT;
     constexpr int SPAN = (T - 1) * D + M * P;      // input samples one tile needs
@@ -229,7 +244,7 @@ __device__ __forceinline__ void pfb_body(
         reinterpret_cast<float*>(tw3_s)[i] = twM[2 * j + (i & 1)];
     }
 
-    const uint32_t t_begin = blockIdx.x * tiles_per_wg;
+    const uint32_t t_begin = bid * tiles_per_wg;
     uint32_t t_end = t_begin + tiles_per_wg;
     if (t_end > n_tiles) t_end = n_tiles;
     if (t_begin >= t_end) return;
@@ -638,7 +653,7 @@ __device__ __forceinline__ void pfb_body(
 }
 
 #define SNOUT_PFB_ARGS                                                                                   \
-    const void* __restrict__ x, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,      \
+    PfbSegs segs, uint64_t n, uint64_t n_out, uint32_t n_tiles, uint32_t tiles_per_wg,                    \
     const float* __restrict__ proto, const float* __restrict__ twM, const float* __restrict__ tw5g,        \
     float2* __restrict__ y, uint64_t y_stride, uint16_t* __restrict__ planes16, uint64_t plane_stride, PfbZbOut zb
 // Register budgets: M = 40 needs 4 wave slots per SIMD (<= 128 VGPRs) or a second 5-wave workgroup does not fit
@@ -651,7 +666,7 @@ template <int M, bool FUSED, int FMT>
 __global__ __launch_bounds__(PfbGeom<M>::NT) __attribute__((amdgpu_waves_per_eu((FUSED && M == 16) ? SNOUT_PFB_WPE_ZB : SNOUT_PFB_WPE)))
 void pfb_channelize(SNOUT_PFB_ARGS)
 {
-    pfb_body<M, FUSED, FMT>(x, n, n_out, n_tiles, tiles_per_wg, proto, twM, tw5g, y, y_stride, planes16, plane_stride, zb);
+    pfb_body<M, FUSED, FMT>(segs, n, n_out, n_tiles, tiles_per_wg, proto, twM, tw5g, y, y_stride, planes16, plane_stride, zb);
 }
 
 // =============================================================================================
@@ -700,6 +715,21 @@ uint64_t PfbCtx::n_out_for(uint64_t n) const
 int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride,
                 const PfbZbTarget* zbt, int fmt)
 {
+    return run_batch(&d_iq, 1, n, st, planes16, plane_stride, 0, zbt, 0, 0, fmt);
+}
+
+// `count` segments of n samples each in ONE launch: segment k reads iqs[k] and writes its bit planes
+// planes_seg uint16 further than segment k - 1 (fused BTLE), its discriminator rows / sub-block sums
+// d_seg floats / S_seg doubles further (fused 802.15.4).  A launch per 2^24-sample segment spends a third of
+// its time in prologues and in the last, partly filled round of tiles; four segments per launch do not.
+int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStream_t st, uint16_t* planes16,
+                      uint64_t plane_stride, uint64_t planes_seg, const PfbZbTarget* zbt, uint64_t d_seg,
+                      uint64_t S_seg, int fmt)
+{
+    if (count == 0 || count > kMaxBatch || (count > 1 && !planes16 && !zbt)) return SNOUT_EINVAL;
+    PfbSegs segs{};
+    for (uint32_t k = 0; k < count; k++) segs.x[k] = iqs[k];
+    segs.planes_seg = planes_seg; segs.d_seg = d_seg; segs.S_seg = S_seg;
     n_out = n_out_for(n);
     y_stride = (n_out + 64 + 1) & ~1ull;      // even: channel rows stay 16-byte aligned
     if (!planes16 && !zbt) { if (int rc = d_y.ensure(y_stride * M * 8u)) return rc; }
@@ -707,7 +737,7 @@ int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16
     if (zbt) zb = PfbZbOut{zbt->d, zbt->d_stride, zbt->S, zbt->nsb, zbt->atan_tab, zbt->iir_w};
     if (n_out == 0) return 0;
 #define SNOUT_PFB_F(MM, FU, F, Y, YS, PL, PS)                                                          \
-    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(nwg), dim3(PfbGeom<MM>::NT), 0, st, d_iq, n, n_out, \
+    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(nwg * count), dim3(PfbGeom<MM>::NT), 0, st, segs, n, n_out, \
                        n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), Y, YS, PL, PS, zb)
 #define SNOUT_PFB(MM, FU, Y, YS, PL, PS)                                                               \
     do {                                                                                              \
@@ -723,8 +753,9 @@ int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16
     // them; a 514-workgroup grid takes 5.9 ms instead of 3.8).
     if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
-        const uint32_t blocks40 = grid_blocks ? grid_blocks : 512u;
+        const uint32_t blocks40 = std::max(1u, (grid_blocks ? grid_blocks : 512u) / count);     // per segment
         const uint32_t tpw = cdiv(n_tiles, blocks40), nwg = cdiv(n_tiles, tpw);
+        segs.wgs_per_seg = nwg;
         if (planes16)
             SNOUT_PFB(40, true, (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
@@ -734,14 +765,16 @@ int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16
         // 256-thread workgroups: four per CU fit (128 VGPRs, 29 KB LDS).  The fused 802.15.4 variant
         // is built for three waves per SIMD instead (148 VGPRs, nothing spilled; at 128 it spilled 15
         // registers inside the tile loop): three workgroups per CU, 1.05 ms instead of 1.18 ms.
-        const uint32_t blocks16 = grid_blocks ? grid_blocks : (zbt ? 768u : 1024u);     // 4-wave workgroups place evenly
+        const uint32_t blocks16 = std::max(1u, (grid_blocks ? grid_blocks : (zbt ? 768u : 1024u)) / count);     // 4-wave workgroups place evenly
         const uint32_t tpw = cdiv(n_tiles, blocks16), nwg = cdiv(n_tiles, tpw);
+        segs.wgs_per_seg = nwg;
         if (zbt) {
             // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
             const uint64_t done = (uint64_t)n_tiles * PfbGeom<16>::T;
             if (done < zbt->d_stride)
-                SNOUT_HIP(hipMemset2DAsync(zbt->d + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
-#define SNOUT_PFB_ZB(F) hipLaunchKernelGGL((pfb_channelize<16, true, F>), dim3(nwg), dim3(PfbGeom<16>::NT), 0, st, d_iq, n, n_out, \
+                for (uint32_t k = 0; k < count; k++)
+                    SNOUT_HIP(hipMemset2DAsync(zbt->d + (uint64_t)k * d_seg + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
+#define SNOUT_PFB_ZB(F) hipLaunchKernelGGL((pfb_channelize<16, true, F>), dim3(nwg * count), dim3(PfbGeom<16>::NT), 0, st, segs, n, n_out, \
             n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0, zb)
             if (fmt == kFmtSc8) SNOUT_PFB_ZB(kFmtSc8);
             else if (fmt == kFmtSc16) SNOUT_PFB_ZB(kFmtSc16);

@@ -174,18 +174,18 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
             zt = z.pfb_target();
         }
         SNOUT_HIP(hipEventRecord(s.ev_k0, st));
-        if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
-                                bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr, ch_fmt)) return rc;
-        // the other segments of a batch: the same channelizer launch into their own rows of the context
-        for (uint32_t k = 1; k < s.segs.count; k++) {
+        if (s.segs.count > 1) {
+            // a batch: every segment's channelizer pass in one launch, outputs one segment stride apart
             if (fused) {
-                uint16_t* planes_k = bw.d_planes.as<uint16_t>() + (uint64_t)k * bw.seg_slots * bw.plane_stride * 4u;
-                if (int rc = h->pfb.run(s.iq_more[k], s.n_in, st, planes_k, bw.plane_stride, nullptr, ch_fmt)) return rc;
+                if (int rc = h->pfb.run_batch(s.iq_more, s.segs.count, s.n_in, st, bw.d_planes.as<uint16_t>(), bw.plane_stride,
+                                              (uint64_t)bw.seg_slots * bw.plane_stride * 4u, nullptr, 0, 0, ch_fmt)) return rc;
             } else {
-                zt = zb_of(h, s).pfb_target(k);
-                if (int rc = h->pfb.run(s.iq_more[k], s.n_in, st, nullptr, 0, &zt, ch_fmt)) return rc;
+                const ZbCtx& z = zb_of(h, s);
+                if (int rc = h->pfb.run_batch(s.iq_more, s.segs.count, s.n_in, st, nullptr, 0, 0, n_ch >= 9u ? &zt : nullptr,
+                                              (uint64_t)z.seg_slots * z.d_stride, (uint64_t)z.seg_slots * z.nsb, ch_fmt)) return rc;
             }
-        }
+        } else if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
+                                       bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr, ch_fmt)) return rc;
         ch_fmt = 0;
         SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         ch_iq = (fused_zb && n_ch >= 9u) ? nullptr : h->pfb.d_y.as<float>();
