@@ -21,9 +21,9 @@ nb, nz = xb.numel() // 2, xz.numel() // 2
 srcb = lambda a, b: xb[2 * a:2 * b]
 srcz = lambda a, b: xz[2 * a:2 * b]
 SEG = int(os.environ.get("SEG", str(1 << 24)))
-HB, HZ = int(os.environ.get("HB", "1")), int(os.environ.get("HZ", "1"))
-sb = ShardedScan(0, n_channels=40, seg_len=SEG, handles=HB, batch=int(os.environ.get("BB", "1")))
-sz = ShardedScan(1, n_channels=16, seg_len=SEG, handles=HZ, batch=int(os.environ.get("BZ", "1")), zb_core=int(os.environ.get("ZB_CORE", "0")), zb_warmup=int(os.environ.get("ZB_WARM", "0")))
+HB, HZ = int(os.environ.get("HB", "1")), int(os.environ.get("HZ", "2"))
+sb = ShardedScan(0, n_channels=40, seg_len=SEG, handles=HB, batch=int(os.environ.get("BB", "4")))
+sz = ShardedScan(1, n_channels=16, seg_len=SEG, handles=HZ, batch=int(os.environ.get("BZ", "4")), zb_core=int(os.environ.get("ZB_CORE", "0")), zb_warmup=int(os.environ.get("ZB_WARM", "0")))
 for rep in range(2):
     sa, sb2, sc = {}, {}, {}
     a = sb.run(nb, srcb, stats=sa)

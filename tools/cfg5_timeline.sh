@@ -13,7 +13,7 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].spli
 ev.sort()
 # the timed region: the last 6 steps = the last 6 x 48 launches of the 40-channel channelizer
 p40 = [e[0] for e in ev if e[2].startswith("void pfb_channelize<40")]
-lo = p40[-6 * 48]
+lo = p40[-(len(p40) * 6 // 9)]
 ev = [e for e in ev if e[0] >= lo]
 span = max(e[1] for e in ev) - min(e[0] for e in ev)
 pts = []
