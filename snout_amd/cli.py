@@ -81,18 +81,18 @@ def main():
 FORMATS = {"cf32": 0, "sc8": 1, "sc16": 2}
 
 
-def _source(proto, iq, synthetic, channels, seconds, fmt="cf32", wideband=False, sharded=False, segment=1 << 24):
+def _source(proto, iq, synthetic, channels, seconds, fmt="cf32", wideband=False, sharded=False, segment=1 << 24, batch=4):
     if wideband or sharded:
         pid = 0 if proto == "btle" else 1
         if iq:
-            return WidebandSource(iq, pid, FORMATS[fmt], segment=segment, sharded=sharded)
+            return WidebandSource(iq, pid, FORMATS[fmt], segment=segment, sharded=sharded, batch=batch)
         if not synthetic:
             raise click.UsageError("give --iq FILE or --synthetic (no live SDR in this build)")
         M = 40 if pid == 0 else 16
         x, _ = synth.wideband_capture(pid, int(seconds * M * 2e6) // M * M, seed=3 + pid)
         if fmt != "cf32":
             x = synth.quantize(x, FORMATS[fmt]).reshape(-1, 2)
-        return WidebandSource(x, pid, FORMATS[fmt], segment=segment, sharded=sharded)
+        return WidebandSource(x, pid, FORMATS[fmt], segment=segment, sharded=sharded, batch=batch)
     if iq:
         return FileSource(iq, FORMATS[fmt])
     if not synthetic:
@@ -117,6 +117,8 @@ def _scan_options(f):
                      help="wideband: cut the capture into overlapping segments, one GPU per rank "
                           "(run under torch.distributed.run), records gathered on rank 0"),
         click.option("--segment", type=int, default=1 << 24, help="wideband: input samples per segment"),
+        click.option("--batch", type=click.IntRange(1, 8), default=4,
+                     help="wideband: segments handed to the GPU as one submission"),
         click.option("-f", "--filename", default=None, help="dump file"),
         click.option("--iq", type=click.Path(exists=True), default=None, help="capture file"),
         click.option("--format", "fmt", type=click.Choice(sorted(FORMATS)), default="cf32",
@@ -136,11 +138,11 @@ def btle():
 @btle.command("scan")
 @_scan_options
 @click.option("--summary", is_flag=True, help="print the device table at the end (snout/util/btle.py:202-240)")
-def btle_scan(channels, active, packets, timeout, wideband, sharded, segment, filename, iq, fmt, synthetic,
+def btle_scan(channels, active, packets, timeout, wideband, sharded, segment, batch, filename, iq, fmt, synthetic,
               seconds, summary):
     chs = parse_channels(channels, "btle")
     packets, timeout = stop_conditions("btle", packets, timeout)
-    scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment),
+    scan = BtleScan(channels=chs, source=_source("btle", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment, batch),
                     timeout=timeout, packet_threshold=packets, filename=filename)
     scan.events.on("btle.packet-received",
                    lambda message: click.echo(message.raw.decode().rstrip("\n")))
@@ -159,11 +161,11 @@ def zigbee():
 @zigbee.command("scan")
 @_scan_options
 @click.option("--udp", is_flag=True, help="send RFtap datagrams to 127.0.0.1:52002 (scapy-radio)")
-def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, filename, iq, fmt, synthetic,
+def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, batch, filename, iq, fmt, synthetic,
                 seconds, udp):
     chs = parse_channels(channels, "zigbee")
     packets, timeout = stop_conditions("zigbee", packets, timeout)
-    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment),
+    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment, batch),
                       timeout=timeout, packet_threshold=packets, udp=udp)
     def show(message):
         from .formats import parse_mhr

@@ -73,13 +73,14 @@ class WidebandSource(IqSource):
     the scan loop channel by channel, in capture order."""
 
     def __init__(self, capture, proto: int, sample_format: int = 0, segment: int = 1 << 24,
-                 sharded: bool = False, device: int = -1):
+                 sharded: bool = False, device: int = -1, batch: int = 4):
         self.capture = capture            # path of a capture file, or an array (complex64 / int pairs)
         self.proto = int(proto)
         self.sample_format = int(sample_format)
         self.segment = int(segment)
         self.sharded = bool(sharded)
         self.device = device
+        self.batch = max(1, min(8, int(batch)))   # segments per submission (snout_rx_submit_batch_dev)
         self.rank = 0
         self._rec = None
 
@@ -106,7 +107,7 @@ class WidebandSource(IqSource):
         dev = torch.device("cuda", torch.cuda.current_device())
         M = 40 if self.proto == _ffi.PROTO_BTLE else 16
         sc = ShardedScan(self.proto, n_channels=M, seg_len=self.segment, device=self.device,
-                         sample_format=self.sample_format)
+                         batch=self.batch, sample_format=self.sample_format)
 
         def source(a, b):
             chunk = np.ascontiguousarray(x[a:b])
