@@ -56,3 +56,7 @@ print("CUs seen %d; max overlapping workgroups per CU: histogram" % len(load), s
 for L in sorted(set(load.values())):
     idx = [i for k, v in byk.items() if load[k] == L for i in v]
     print("  CUs with %d resident: %d workgroups, run time median %.0f us, last end %.0f us" % (L, len(idx), np.median((end - start)[idx]), end[idx].max()))
+ok = tt[:, 1] > tt[:, 0]
+dur = (end - start)[ok]
+e = end[ok] - start[ok].min()
+print("workgroup run time (us): min %.0f p10 %.0f median %.0f p90 %.0f max %.0f; last end - median end = %.0f us (%.1f %% of the kernel)" % (dur.min(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(), e.max() - np.median(e), 100 * (e.max() - np.median(e)) / e.max()))
