@@ -130,3 +130,24 @@ def test_poll_tells_when_collect_will_not_wait(capture):
         assert time.time() - t0 < 30
         time.sleep(0.0005)
     assert len(rx.collect()) > 0 and rx.ready() is False
+
+
+def test_batch_survives_a_capacity_rerun():
+    """A batch whose candidates outgrow the provisioned capacity is run again as a whole with more room
+    (the same rerun a single segment gets): records unchanged."""
+    import torch
+    from snout_amd import synth
+    from snout_amd.rx import SnoutRx
+    x, _ = synth.wideband_capture(0, 40 * (1 << 16), seed=23, sigma=0.02, mean_gap=3000.0)
+    cap = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    n = cap.numel() // 2 // 3 // 40 * 40
+    xs = [cap[2 * k * n:2 * (k + 1) * n] for k in range(3)]
+    firsts = [k * n // 20 for k in range(3)]
+    one = SnoutRx(proto=0, n_channels=40)
+    ref = np.concatenate([one.process(xk, first_sample_index=f) for xk, f in zip(xs, firsts)])
+    assert len(ref) > 200
+    small = SnoutRx(proto=0, n_channels=40, batch_segments=3, max_hits=64)     # far fewer than the candidates
+    for _ in range(2):                                                          # the grown capacity is kept
+        small.submit_batch(xs, firsts)
+        got = small.collect()
+        assert got.tobytes() == ref.tobytes()
