@@ -17,6 +17,20 @@ from ._ffi import PKT_DTYPE
 REC = PKT_DTYPE.itemsize  # 160
 
 
+def group_submissions(segs, batch: int):
+    """Runs of up to ``batch`` consecutive segments of EQUAL length: what one
+    ``snout_rx_submit_batch_dev`` call may carry.  Returns lists of indices into ``segs``; a segment of
+    another length (the first one of a pre-rolled scan, the last one of a capture) starts a new run."""
+    batch = max(1, int(batch))
+    runs = []
+    for j, (a, b) in enumerate(segs):
+        if runs and len(runs[-1]) < batch and (b - a) == (segs[runs[-1][0]][1] - segs[runs[-1][0]][0]):
+            runs[-1].append(j)
+        else:
+            runs.append([j])
+    return runs
+
+
 def shard_segments(n_total: int, seg_len: int, overlap: int, rank: int, world: int,
                    preroll: int = 0) -> List[Tuple[int, int]]:
     """Cut [0, n_total) into segments of seg_len samples that each extend `overlap` samples into

@@ -87,12 +87,7 @@ class ShardedScan:
         self._sink = sink
         self._appended = [None] * len(self.rxs)     # event behind the last device-side append of each handle
         # submissions: runs of up to `batch` consecutive segments of equal length
-        self._subs = []
-        for j, (a, b) in enumerate(self._segs):
-            if self._subs and len(self._subs[-1]) < self.batch and (b - a) == (self._segs[self._subs[-1][0]][1] - self._segs[self._subs[-1][0]][0]):
-                self._subs[-1].append(j)
-            else:
-                self._subs.append([j])
+        self._subs = sdist.group_submissions(self._segs, self.batch)
         self._next = 0                  # next submission
         self._done = 0                  # submissions collected
         self._alive = {}                # submission index -> tensors (kept until collected)

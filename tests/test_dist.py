@@ -22,6 +22,25 @@ def test_shard_segments_cover_everything_once():
         assert max(counts) - min(counts) <= 1
 
 
+def test_group_submissions_batches_equal_lengths_in_order():
+    """What one batched submission may carry: consecutive segments of equal length, at most `batch`."""
+    n, seg, ov, pre = 10_000, 1024, 100, 256
+    for world in (1, 2, 3):
+        for rank in range(world):
+            segs = sdist.shard_segments(n, seg, ov, rank, world, pre)
+            for batch in (1, 2, 4, 8):
+                runs = sdist.group_submissions(segs, batch)
+                assert [j for run in runs for j in run] == list(range(len(segs)))          # every segment once, in order
+                assert all(1 <= len(run) <= batch for run in runs)
+                for run in runs:
+                    assert len({segs[j][1] - segs[j][0] for j in run}) == 1                  # equal lengths inside a run
+                for a, b in zip(runs, runs[1:]):                                             # runs are maximal
+                    same = segs[b[0]][1] - segs[b[0]][0] == segs[a[0]][1] - segs[a[0]][0]
+                    assert not same or len(a) == batch
+    assert sdist.group_submissions([], 4) == []
+    assert sdist.group_submissions([(0, 10), (10, 20), (20, 25), (25, 35)], 4) == [[0, 1], [2], [3]]
+
+
 def _recs(keys):
     r = np.zeros(len(keys), dtype=PKT_DTYPE)
     for i, (p, c, s) in enumerate(keys):
