@@ -426,6 +426,8 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
                "ms_per_step": dt / steps * 1e3, "steps": steps,
                "samples_per_gpu": nb_rank + nz_rank, "btle_samples_per_gpu": nb_rank, "zigbee_samples_per_gpu": nz_rank,
                "segments_per_gpu": len(sb._segs) + len(sz._segs), "segment_samples": SEG,
+               "segments_per_submission": {"btle": sb.batch, "zigbee": sz.batch},
+               "value_per_gpu": total / dt / 1e6 / world,
                "records_on_rank0": int(len(rb) + len(rz)), "decoded_crc_ok": ok_b + ok_z,
                "expected_crc_ok": exp_b + exp_z, "decoded_pkts_per_s": (len(rb) + len(rz)) * steps / dt,
                "sharding": "segment i -> rank i mod N; per step one all_gather of 80-B BTLE and one of 160-B "
