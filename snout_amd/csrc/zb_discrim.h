@@ -12,7 +12,7 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     // Straight-line form of the oracle's branches (same operations on the taken path, selected).
     const float ya = fabsf(y), xa = fabsf(x);
     const bool lt = ya < xa;
-    const float z = (lt ? ya : xa) / (lt ? xa : ya);         // 0/0 -> NaN, replaced below
+    const float z = (lt ? ya : xa) / (lt ? xa : ya);         // 0/0 -> NaN, see the end
     const float a = z * 255.0f;
     const int k = ((int)a) & 0xff;
     const float t0 = tab[k];
@@ -24,11 +24,14 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     // H - base | H + base (otherwise): base - PI == -(PI - base), -H + base == -(H - base) and
     // -H - base == -(H + base) exactly (rounding is symmetric), so one magnitude and the sign of
     // "y >= 0" (a compare, not the sign bit: -0.0 counts as non-negative) give the same bits.
-    const float m_lt = xp ? base : PI - base;
-    const float m_ge = xp ? H - base : H + base;
-    const float m = lt ? m_lt : m_ge;
-    const float ang = __uint_as_float(__float_as_uint(m) ^ (yp ? 0u : 0x80000000u));
-    return (ya > 0.0f || xa > 0.0f) ? ang : 0.0f;
+    // The magnitude itself is c + s base with c = 0 | PI | H and s = -1 where exactly one of
+    // (|y| < |x|), (x >= 0) holds: a - b and a + (-b) round alike and 0 + base is base.
+    const float c = lt ? (xp ? 0.0f : PI) : H;
+    const float sb = __uint_as_float(__float_as_uint(base) ^ ((lt != xp) ? 0x80000000u : 0u));
+    const float m = c + sb;
+    // x == y == 0 gives z = 0/0 = NaN and a NaN angle here: the caller's finiteness test turns it into
+    // the 0 the oracle returns for that case
+    return __uint_as_float(__float_as_uint(m) ^ (yp ? 0u : 0x80000000u));
 }
 
 
