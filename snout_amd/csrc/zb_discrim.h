@@ -14,7 +14,9 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     const bool lt = ya < xa;
     const float z = (lt ? ya : xa) / (lt ? xa : ya);         // 0/0 -> NaN, see the end
     const float a = z * 255.0f;
-    const int k = ((int)a) & 0xff;
+    // the oracle's "& 0xff" is the identity here: z is a minimum over a maximum, in [0, 1] or NaN, so a is in
+    // [0, 255] or NaN and v_cvt_i32_f32 gives 0..255 (NaN -> 0)
+    const int k = (int)a;
     const float t0 = tab[k];
     const float interp = t0 + (tab[k + 1] - t0) * (a - (float)k);
     const float base = z < 0.003921569f ? z : interp;
