@@ -540,13 +540,23 @@ __device__ __forceinline__ void pfb_body(
             float2 p = seg ? col[(8 * seg - 1) * ROW] : prevy[k];
             float dv[8];
             const uint32_t left = n_out > m0 ? (uint32_t)(n_out - m0 < (uint64_t)T ? n_out - m0 : (uint64_t)T) : 0u;   // outputs of this tile that exist (uniform)
+            if (left >= (uint32_t)T) {                                // every tile but the last: no range test per sample
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float2 a = col[(8 * seg + j) * ROW];
-                const float v = zb_discriminate(a, p, atan_s);
-                dv[j] = ((uint32_t)(8 * seg + j) < left) ? v : 0.0f;
-                dl[k * DLROW + 8 * seg + j] = dv[j];
-                p = a;
+                for (int j = 0; j < 8; j++) {
+                    const float2 a = col[(8 * seg + j) * ROW];
+                    dv[j] = zb_discriminate(a, p, atan_s);
+                    dl[k * DLROW + 8 * seg + j] = dv[j];
+                    p = a;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float2 a = col[(8 * seg + j) * ROW];
+                    const float v = zb_discriminate(a, p, atan_s);
+                    dv[j] = ((uint32_t)(8 * seg + j) < left) ? v : 0.0f;
+                    dl[k * DLROW + 8 * seg + j] = dv[j];
+                    p = a;
+                }
             }
             const bool emit = tile >= t_begin;                        // the tile before the range only primes prevy
             if (emit) {

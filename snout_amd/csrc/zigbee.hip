@@ -80,7 +80,6 @@ __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, u
         const uint64_t t0 = chunk * 1024u + 4u * threadIdx.x;      // this thread's 4 samples
         float ang[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (t0 < n) {
-            const uint32_t left = n - t0 < 4u ? (uint32_t)(n - t0) : 4u;     // samples of the quad that exist
             float2 xs[5];
             xs[0] = t0 ? iq_sample<FMT>(x, t0 - 1u) : make_float2(0.0f, 0.0f);
             if (t0 + 3u < n) {
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void zb_discrim(const void* __restrict__ iq, u
                 const float im = a.y * p.x - a.x * p.y;
                 float v = fast_atan2f_tab(im, re, tab);
                 if (!(fabsf(v) <= 4.0f)) v = 0.0f;              // non-finite input: defined as 0 (as the oracle)
-                ang[k] = k < left ? v : 0.0f;
+                ang[k] = v;                                     // (a sample past n was loaded as 0: 0/0 -> NaN -> 0)
             }
         }
         *reinterpret_cast<float4*>(&d[(uint64_t)slot * d_stride + t0]) = make_float4(ang[0], ang[1], ang[2], ang[3]);
