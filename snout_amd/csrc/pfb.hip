@@ -159,7 +159,18 @@ struct PfbSegs {
 };
 
 template <int M> struct PfbGeom;
+#ifndef SNOUT_PFB_T64
+// 128 output times per tile: half the barriers per output of a 64-time tile, and one FIR window of 31
+// samples serves 16 outputs where two windows of 23 served 8 each (3.47 -> 3.27 ms per 8e8 samples)
+#define SNOUT_PFB_T128 1
+template <> struct PfbGeom<40> { static constexpr int T = 128, M1 = 8, M2 = 5, NT = 320; };
+extern __shared__ float4 pfb_dyn_lds[];
+#else
 template <> struct PfbGeom<40> { static constexpr int T = 64,  M1 = 8, M2 = 5, NT = 320; };
+#endif
+#if defined(SNOUT_PFB_NO_FUSE3B) && defined(SNOUT_PFB_T128)
+#error "the separate slicer pass (SNOUT_PFB_NO_FUSE3B) is written for 64-time tiles: add -DSNOUT_PFB_T64"
+#endif
 template <> struct PfbGeom<16> { static constexpr int T = 128, M1 = 4, M2 = 4, NT = 256; };
 
 // One workgroup walks a contiguous range of tiles of T output times.  Consecutive tiles share
@@ -209,7 +220,14 @@ __device__ __forceinline__ void pfb_body(
 #else
     constexpr bool FUSE3B = FUSED && M == 40;      // BTLE: pass 3b decides the hard bits in registers
 #endif
+#ifdef SNOUT_PFB_T128
+    // M = 40: in dynamic LDS (42 KB) -- static LDS of this size makes the compiler raise next_free_vgpr to an
+    // occupancy it derives from it, and the second workgroup no longer fits the CU (profiles/r2_pfb_experiments.md)
+    __shared__ float2 us_static[M == 40 ? 1 : T * ROW];
+    float2* const us = M == 40 ? reinterpret_cast<float2*>(pfb_dyn_lds) : us_static;
+#else
     __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
+#endif
     constexpr int DLROW = T + 1;                   // padded row of the tile's d values (S_j reads)
     static_assert(!ZB || (M * DLROW <= 2 * SPAN && T == 128 && NT == 256), "d tile reuses the input span");
     __shared__ float atan_s[ZB ? 257 : 1];
@@ -313,7 +331,47 @@ __device__ __forceinline__ void pfb_body(
     };
     auto do_fir = [&]() {
         // ---- 2. FIR: outputs m = e + 2 (8 grp + i) of branch r: a sliding dot product
-        {
+        constexpr int OUT = T / (2 * (NT / (2 * M)));         // outputs per (branch, parity, group): 8, or 16
+        if constexpr (OUT == 16) {
+            // m = e + 2 (16 grp + i), i = 0..15: one window of 31 samples; the first four outputs need samples
+            // 0..18, every further four outputs four more, read while the four before them are computed
+            const int base = r + e * D + (16 * grp) * M;
+            const uint32_t a0 = (uint32_t)(uintptr_t)&xs[base];
+            v2f wv[16 + P - 1];
+#pragma unroll
+            for (int q = 0; q < 19; q++)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                           "+v"(wv[7]), "+v"(wv[8]), "+v"(wv[9]), "+v"(wv[10]), "+v"(wv[11]), "+v"(wv[12]),
+                           "+v"(wv[13]), "+v"(wv[14])
+                         :: "memory");
+            asm volatile("" : "+v"(wv[15]), "+v"(wv[16]), "+v"(wv[17]), "+v"(wv[18]) :: "memory");
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 4) {
+                if (i0 < 12) {
+#pragma unroll
+                    for (int q = i0 + 19; q < i0 + 23; q++)
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+                }
+                v2f acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc[j]) : "v"(hp[0]), "v"(wv[i0 + j]));
+#pragma unroll
+                for (int p = 1; p < P; p++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (p & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(wv[i0 + j + p]));
+                        else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(wv[i0 + j + p]));
+                    }
+                }
+                if (i0 < 12)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[i0 + 19]), "+v"(wv[i0 + 20]), "+v"(wv[i0 + 21]), "+v"(wv[i0 + 22]) :: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; j++) us[(e + 2 * (16 * grp + i0 + j)) * ROW + r] = make_float2(acc[j].x, acc[j].y);
+            }
+        } else {
             const int base = r + e * D + (8 * grp) * M;       // tile-relative index of z[8 grp]
             float2 w[8 + P - 1];
 #ifdef SNOUT_PFB_NOREAD2
@@ -440,10 +498,18 @@ __device__ __forceinline__ void pfb_body(
             //      lanes come out of v_cmp as a wave mask; lanes (k2, k1 half g, a) pick the 2 x 8 bits of
             //      their channel and phase out of the masks and interleave them into the 16-bit quarter
             //      of the plane word.
+            // (T = 128: the tile is two such halves of 64 output times, one after the other; of the tile
+            //  behind the range only the first half is needed, to complete the range's last symbols)
+#pragma unroll
+            for (int hv = 0; hv < T / 64; hv++) {
+            if (hv == 1 && tile >= t_end) break;
+            const uint64_t m0v = m0 + 64u * (uint32_t)hv;
+            const float2* usv = us + 64 * hv * ROW;
+            const bool last_half = tile + 1u == n_tiles && hv == T / 64 - 1;
 #ifdef SNOUT_ABL_NO3B
             if (n == 0x123456789ull) {             // timing experiment: never true
 #else
-            if (t < (T / 2) * M1) {
+            if (t < 32 * M1) {
 #endif
                 const int mp = t & 31, k1 = t >> 5, a = mp & 3, b = mp >> 2;
                 const int mA = a + 8 * b;
@@ -451,10 +517,10 @@ __device__ __forceinline__ void pfb_body(
                 {
                     cf bb[M2];
 #pragma unroll
-                    for (int n2 = 0; n2 < M2; n2++) { const float2 v = us[mA * ROW + M2 * k1 + n2]; bb[n2] = cf{v.x, v.y}; }
+                    for (int n2 = 0; n2 < M2; n2++) { const float2 v = usv[mA * ROW + M2 * k1 + n2]; bb[n2] = cf{v.x, v.y}; }
                     dft5(bb, YA, c5_1, c5_2, s5_1, s5_2);
 #pragma unroll
-                    for (int n2 = 0; n2 < M2; n2++) { const float2 v = us[(mA + 4) * ROW + M2 * k1 + n2]; bb[n2] = cf{v.x, v.y}; }
+                    for (int n2 = 0; n2 < M2; n2++) { const float2 v = usv[(mA + 4) * ROW + M2 * k1 + n2]; bb[n2] = cf{v.x, v.y}; }
                     dft5(bb, YB, c5_1, c5_2, s5_1, s5_2);
                 }
                 const int src = ((t & 32) | ((t + 4) & 31)) << 2;         // lane of (a, b + 1 mod 8, k1)
@@ -482,21 +548,22 @@ __device__ __forceinline__ void pfb_body(
                     const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;              // bits exist for m < n_out-4
                     const int k = 2 * (t >> 6) + g + M1 * k2s;
                     if (have_prev) {
-                        const uint64_t mprev = m0 - 4u + (uint64_t)j;                // sample of the carried symbol
+                        const uint64_t mprev = m0v - 4u + (uint64_t)j;                // sample of the carried symbol
                         const uint32_t b15 = (mprev < nbits) ? (c >> 15) : 0u;
-                        const uint64_t mq = m0 - (uint64_t)T;                        // first sample of the previous tile
+                        const uint64_t mq = m0v - 64u;                               // first sample of the previous 64 output times
                         planes16[((uint64_t)k * plane_stride + (mq >> 8) * 4u + (uint32_t)j) * 4u +
                                  (uint32_t)((mq & 255u) >> 6)] = (uint16_t)(pend | (b15 << 15));
                     }
-                    const uint32_t left = nbits > m0 ? (uint32_t)(nbits - m0 < 64u ? nbits - m0 : 64u) : 0u;   // uniform
+                    const uint32_t left = nbits > m0v ? (uint32_t)(nbits - m0v < 64u ? nbits - m0v : 64u) : 0u;   // uniform
                     const uint32_t cnt = left > (uint32_t)j ? (left - (uint32_t)j + 3u) >> 2 : 0u;
                     pend = c & ((1u << (cnt < 15u ? cnt : 15u)) - 1u);
-                    if (tile + 1u == n_tiles)                                        // no later tile: symbol 15 has no partner
-                        planes16[((uint64_t)k * plane_stride + (m0 >> 8) * 4u + (uint32_t)j) * 4u +
-                                 (uint32_t)((m0 & 255u) >> 6)] = (uint16_t)pend;
+                    if (last_half)                                                   // no later tile: symbol 15 has no partner
+                        planes16[((uint64_t)k * plane_stride + (m0v >> 8) * 4u + (uint32_t)j) * 4u +
+                                 (uint32_t)((m0v & 255u) >> 6)] = (uint16_t)pend;
                 }
                 have_prev = true;
             }
+            }   // halves
         } else
         for (int it = t; it < (T / 2) * M1; it += NT) {
             const int mp = it % (T / 2), k1 = it / (T / 2);
@@ -684,6 +751,12 @@ void pfb_channelize(SNOUT_PFB_ARGS)
 // =============================================================================================
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+#ifdef SNOUT_PFB_T128
+#define SNOUT_PFB_DYN_LDS(MM) ((MM) == 40 ? (size_t)PfbGeom<40>::T * 41u * 8u : (size_t)0)
+#else
+#define SNOUT_PFB_DYN_LDS(MM) 0
+#endif
+
 #ifdef SNOUT_PFB_STAMPS
 extern "C" int snout_debug_pfb_times(unsigned long long* out, uint32_t n)
 {
@@ -747,7 +820,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     if (zbt) zb = PfbZbOut{zbt->d, zbt->d_stride, zbt->S, zbt->nsb, zbt->atan_tab, zbt->iir_w};
     if (n_out == 0) return 0;
 #define SNOUT_PFB_F(MM, FU, F, Y, YS, PL, PS)                                                          \
-    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(nwg * count), dim3(PfbGeom<MM>::NT), 0, st, segs, n, n_out, \
+    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(nwg * count), dim3(PfbGeom<MM>::NT), SNOUT_PFB_DYN_LDS(MM), st, segs, n, n_out, \
                        n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), Y, YS, PL, PS, zb)
 #define SNOUT_PFB(MM, FU, Y, YS, PL, PS)                                                               \
     do {                                                                                              \
