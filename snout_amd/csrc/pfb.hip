@@ -229,7 +229,7 @@ __device__ __forceinline__ void pfb_body(
     __shared__ float2 us[T * ROW];                 // FIR outputs u_m[r]; both FFT passes work in place
 #endif
     constexpr int DLROW = T + 1;                   // padded row of the tile's d values (S_j reads)
-    static_assert(!ZB || (M * DLROW <= 2 * SPAN && T == 128 && NT == 256), "d tile reuses the input span");
+    static_assert(!ZB || (M * DLROW <= 2 * SPAN && T % 128 == 0 && NT == 256), "d tile reuses the input span");
     __shared__ float atan_s[ZB ? 257 : 1];
     __shared__ double wts_s[ZB ? 64 : 1];
     __shared__ float2 prevy[ZB ? M : 1];           // y[m0 - 1] of every channel
@@ -599,43 +599,45 @@ __device__ __forceinline__ void pfb_body(
 
         if constexpr (ZB) {
             lds_barrier();
-            // ---- 4z. discriminator.  Thread <-> (channel k, output times 8 seg .. 8 seg + 7); channel
+            // ---- 4z. discriminator.  Thread <-> (channel k, output times TPT seg .. TPT seg + TPT - 1); channel
             //      k = k1 + M1 k2 sits in slot M2 k1 + k2 of every row.
+            constexpr int TPT = T / (NT / M);                         // output times per thread: 8 (T = 128) or 16
             float* dl = reinterpret_cast<float*>(xs);                 // [k][DLROW]: the span is dead here
             const int k = t & (M - 1), seg = t / M;
             const float2* col = &us[M2 * (k % M1) + (k / M1)];
-            float2 p = seg ? col[(8 * seg - 1) * ROW] : prevy[k];
-            float dv[8];
+            float2 p = seg ? col[(TPT * seg - 1) * ROW] : prevy[k];
+            float dv[TPT];
             const uint32_t left = n_out > m0 ? (uint32_t)(n_out - m0 < (uint64_t)T ? n_out - m0 : (uint64_t)T) : 0u;   // outputs of this tile that exist (uniform)
             if (left >= (uint32_t)T) {                                // every tile but the last: no range test per sample
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float2 a = col[(8 * seg + j) * ROW];
+                for (int j = 0; j < TPT; j++) {
+                    const float2 a = col[(TPT * seg + j) * ROW];
                     dv[j] = zb_discriminate(a, p, atan_s);
-                    dl[k * DLROW + 8 * seg + j] = dv[j];
+                    dl[k * DLROW + TPT * seg + j] = dv[j];
                     p = a;
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float2 a = col[(8 * seg + j) * ROW];
+                for (int j = 0; j < TPT; j++) {
+                    const float2 a = col[(TPT * seg + j) * ROW];
                     const float v = zb_discriminate(a, p, atan_s);
-                    dv[j] = ((uint32_t)(8 * seg + j) < left) ? v : 0.0f;
-                    dl[k * DLROW + 8 * seg + j] = dv[j];
+                    dv[j] = ((uint32_t)(TPT * seg + j) < left) ? v : 0.0f;
+                    dl[k * DLROW + TPT * seg + j] = dv[j];
                     p = a;
                 }
             }
             const bool emit = tile >= t_begin;                        // the tile before the range only primes prevy
             if (emit) {
-                float* dst = zb.d + (uint64_t)k * zb.d_stride + m0 + (uint64_t)(8 * seg);
-                reinterpret_cast<float4*>(dst)[0] = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                reinterpret_cast<float4*>(dst)[1] = make_float4(dv[4], dv[5], dv[6], dv[7]);
+                float* dst = zb.d + (uint64_t)k * zb.d_stride + m0 + (uint64_t)(TPT * seg);
+#pragma unroll
+                for (int q = 0; q < TPT / 4; q++)
+                    reinterpret_cast<float4*>(dst)[q] = make_float4(dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]);
             }
             lds_barrier();
-            if (seg == T / 8 - 1) prevy[k] = p;                       // y[m0 + T - 1] for the next tile
-            // S_j of the tile's 2 x M sub-blocks (oracle order): four threads per sub-block sum 16
+            if (seg == NT / M - 1) prevy[k] = p;                      // y[m0 + T - 1] for the next tile
+            // S_j of the tile's T / 64 x M sub-blocks (oracle order): four threads per sub-block sum 16
             // terms each in sequence, S = (P0 + P1) + (P2 + P3)
-            if (emit && t < 8 * M) {
+            if (emit && t < (T / 64) * 4 * M) {
                 const int part = t & 3, kk = (t >> 2) & (M - 1), sb = t >> 6;
                 double acc = 0.0;
 #pragma unroll
@@ -845,9 +847,11 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
             SNOUT_PFB(40, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
-        // 256-thread workgroups: four per CU fit (128 VGPRs, 29 KB LDS).  The fused 802.15.4 variant
-        // is built for three waves per SIMD instead (148 VGPRs, nothing spilled; at 128 it spilled 15
-        // registers inside the tile loop): three workgroups per CU, 1.05 ms instead of 1.18 ms.
+        // 256-thread workgroups: four per CU fit (<= 128 VGPRs, 29 KB LDS).  The fused 802.15.4 variant keeps
+        // to three per CU although it would fit four since it is built without the SLP vectorizer (126
+        // registers): one segment at a time 1 024 workgroups are 6 % faster (1.94 -> 1.83 ms per 3.2e8
+        // samples), but in a pipelined scan the chain's other kernels then find no free wave slots beside
+        // the persistent grid, and the step gets 4 % slower (cfg #4: 3.15 -> 3.31 ms; cfg #5 likewise).
         const uint32_t blocks16 = std::max(1u, (grid_blocks ? grid_blocks : (zbt ? 768u : 1024u)) / count);     // 4-wave workgroups place evenly
         const uint32_t tpw = cdiv(n_tiles, blocks16), nwg = cdiv(n_tiles, tpw);
         segs.wgs_per_seg = nwg;
