@@ -134,10 +134,35 @@ struct PfbZbTarget {
     const double* iir_w;
 };
 
+// The segments of one channelizer launch (a batch of equal-length capture segments,
+// snout_rx_submit_batch_dev): the grid is `wgs_per_seg` workgroups per segment; segment k reads x[k] and
+// writes k "seg" strides further.
+struct PfbSegs {
+    const void* x[kMaxBatch];
+    uint32_t wgs_per_seg;
+    uint64_t planes_seg;        // uint16 elements between the bit planes of consecutive segments
+    uint64_t d_seg, S_seg;      // floats / doubles between their discriminator rows / sub-block sums
+};
+
+// Arguments of the matrix-pipe channelizer kernel (pfb_mfma.hip), by value.
+struct PfbMfArgs {
+    PfbSegs segs;
+    uint64_t n, n_out;
+    uint32_t n_tiles, tiles_per_wg;
+    const float* proto;
+    float2* y;
+    uint64_t y_stride;
+    uint16_t* planes16;
+    uint64_t plane_stride;
+};
+// M = 40; btle: hard bits into the planes, else channel IQ into y
+int pfb_mfma_launch(uint32_t M, bool btle, int fmt, uint32_t grid, hipStream_t st, const PfbMfArgs& a);
+
 struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
     uint32_t grid_blocks = 0;        // persistent grid; 0 = what is RESIDENT at once (see PfbCtx::run), else SNOUT_PFB_BLOCKS
+    bool valu_impl = false;          // SNOUT_PFB_IMPL=valu: the M = 40 kernel of pfb.hip instead of pfb_mfma.hip (A/B)
     DevBuf d_proto, d_tw, d_tw5, d_y;
     int init(uint32_t M);
     void destroy();

@@ -149,15 +149,6 @@ struct PfbZbOut {
     const double* iir_w;
 };
 
-// The segments of one launch (a batch of equal-length capture segments, snout_rx_submit_batch_dev): the
-// grid is `wgs_per_seg` workgroups per segment; segment k reads x[k] and writes k "seg" strides further.
-struct PfbSegs {
-    const void* x[kMaxBatch];
-    uint32_t wgs_per_seg;
-    uint64_t planes_seg;        // uint16 elements between the bit planes of consecutive segments
-    uint64_t d_seg, S_seg;      // floats / doubles between their discriminator rows / sub-block sums
-};
-
 template <int M> struct PfbGeom;
 #ifndef SNOUT_PFB_T64
 // 128 output times per tile: half the barriers per output of a 64-time tile, and one FIR window of 31
@@ -774,6 +765,7 @@ int PfbCtx::init(uint32_t M_)
 {
     M = M_;
     if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
+    if (const char* e = getenv("SNOUT_PFB_IMPL")) valu_impl = strcmp(e, "valu") == 0;
     if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
     const float* proto = M == 40 ? kPfbProto40 : kPfbProto16;
     const float* tw = M == 40 ? kTw40 : kTw16;
@@ -836,7 +828,16 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     // them per CU, not the three that 16 slots / 5 waves suggests (census with s_memrealtime stamps,
     // tools/pfb_stamps.py: 512 of 768 workgroups started at once, 2 on every CU, the other 256 after
     // them; a 514-workgroup grid takes 5.9 ms instead of 3.8).
-    if (M == 40) {
+    if (M == 40 && !valu_impl) {
+        // pfb_mfma.hip: one 16-wave workgroup per CU (FIR on the matrix pipe beside the FFT waves), tiles of 128
+        const uint32_t n_tiles = cdiv(n_out, 128u);
+        const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
+        const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
+        segs.wgs_per_seg = nwg;
+        PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), planes16 ? nullptr : d_y.as<float2>(), y_stride,
+                    planes16, plane_stride};
+        return pfb_mfma_launch(40, planes16 != nullptr, fmt, nwg * count, st, a);
+    } else if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
         const uint32_t blocks40 = std::max(1u, (grid_blocks ? grid_blocks : 512u) / count);     // per segment
         const uint32_t tpw = cdiv(n_tiles, blocks40), nwg = cdiv(n_tiles, tpw);
