@@ -156,13 +156,16 @@ struct PfbMfArgs {
     uint64_t plane_stride;
 };
 // M = 40; btle: hard bits into the planes, else channel IQ into y
-int pfb_mfma_launch(uint32_t M, bool btle, int fmt, uint32_t grid, hipStream_t st, const PfbMfArgs& a);
+int pfb_mfma_launch(uint32_t M, bool btle, int fmt, int impl, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // impl: 0 MFMA FIR, 1 VALU FIR
+
+// pfb_spec.hip: 12 specialised waves per CU (FIR + staging | FFT in registers), M = 40
+int pfb_spec_launch(uint32_t M, bool btle, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // waves: 12 or 16 per workgroup
 
 struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
     uint32_t grid_blocks = 0;        // persistent grid; 0 = what is RESIDENT at once (see PfbCtx::run), else SNOUT_PFB_BLOCKS
-    bool valu_impl = false;          // SNOUT_PFB_IMPL=valu: the M = 40 kernel of pfb.hip instead of pfb_mfma.hip (A/B)
+    int impl = 4;                    // SNOUT_PFB_IMPL, M = 40 kernel: 0 valu = pfb.hip, 1 mfma / 2 spec16 = pfb_mfma.hip with its FIR on the matrix / vector pipe, 3 spec12 / 4 spec = pfb_spec.hip with 12 / 16 waves
     DevBuf d_proto, d_tw, d_tw5, d_y;
     int init(uint32_t M);
     void destroy();

@@ -765,7 +765,7 @@ int PfbCtx::init(uint32_t M_)
 {
     M = M_;
     if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
-    if (const char* e = getenv("SNOUT_PFB_IMPL")) valu_impl = strcmp(e, "valu") == 0;
+    if (const char* e = getenv("SNOUT_PFB_IMPL")) impl = strcmp(e, "valu") == 0 ? 0 : (strcmp(e, "mfma") == 0 ? 1 : (strcmp(e, "spec16") == 0 ? 2 : (strcmp(e, "spec12") == 0 ? 3 : 4)));
     if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
     const float* proto = M == 40 ? kPfbProto40 : kPfbProto16;
     const float* tw = M == 40 ? kTw40 : kTw16;
@@ -828,7 +828,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     // them per CU, not the three that 16 slots / 5 waves suggests (census with s_memrealtime stamps,
     // tools/pfb_stamps.py: 512 of 768 workgroups started at once, 2 on every CU, the other 256 after
     // them; a 514-workgroup grid takes 5.9 ms instead of 3.8).
-    if (M == 40 && !valu_impl) {
+    if (M == 40 && impl != 0) {
         // pfb_mfma.hip: one 16-wave workgroup per CU (FIR on the matrix pipe beside the FFT waves), tiles of 128
         const uint32_t n_tiles = cdiv(n_out, 128u);
         const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
@@ -836,7 +836,8 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
         segs.wgs_per_seg = nwg;
         PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), planes16 ? nullptr : d_y.as<float2>(), y_stride,
                     planes16, plane_stride};
-        return pfb_mfma_launch(40, planes16 != nullptr, fmt, nwg * count, st, a);
+        if (impl >= 3) return pfb_spec_launch(40, planes16 != nullptr, fmt, impl == 3 ? 12 : 16, nwg * count, st, a);
+        return pfb_mfma_launch(40, planes16 != nullptr, fmt, impl == 1 ? 0 : 1, nwg * count, st, a);
     } else if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
         const uint32_t blocks40 = std::max(1u, (grid_blocks ? grid_blocks : 512u) / count);     // per segment

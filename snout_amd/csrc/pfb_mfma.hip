@@ -35,6 +35,7 @@
 namespace snout {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 // v_writelane_b32 as the compiler's own instruction (this clang has no __builtin_amdgcn_writelane): as inline
 // asm the hazard recogniser does not see it, and on gfx950 a VALU read of an SGPR needs two wait states behind
 // the v_cmp that wrote it -- the asm form read stale masks wherever the scheduler put the two back to back.
@@ -134,7 +135,13 @@ template <int M> __device__ __forceinline__ uint32_t swz_of(uint32_t P)
 // Output modes of the kernel
 constexpr int kMfIq = 0, kMfBtle = 1;
 
-template <int M, int MODE, int FMT>
+// IMPL: how the front-end waves 0-7 compute the FIR.
+//   kFirMfma: all eight on the matrix pipe (banded-Toeplitz chains), staging on the side
+//   kFirValu: waves 0 .. M/8-1 with packed FMAs (the sliding dot product of pfb.hip: thread <-> branch, parity,
+//             16 outputs), the other front-end waves only stage the input, two tiles ahead
+constexpr int kFirMfma = 0, kFirValu = 1;
+
+template <int M, int MODE, int FMT, int IMPL>
 __global__ __launch_bounds__(mf::kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void pfb_mfma(const PfbMfArgs A)
 {
@@ -177,7 +184,146 @@ void pfb_mfma(const PfbMfArgs A)
     const unsigned long long st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    if (w < kFirWaves) {
+    if (IMPL == kFirValu && w < kFirWaves) {
+        using Raw = typename IqRaw<FMT>::pair;
+        constexpr int NFW = M / 8;                                  // FIR waves: (branch, parity, 4 groups of 16 outputs)
+        static_assert(NFW * 64 == 2 * M * 4 && T == 128, "FIR thread map");
+        if (w < NFW) {
+            // =================================================================================
+            // FIR waves (vector pipe): thread <-> (branch r, output parity e, group grp): the 16 outputs
+            // m = e + 2 (16 grp + i) of one branch are a sliding dot product over z[q] = x[r + e D + q M]
+            // =================================================================================
+            const int tf = w * 64 + l, r = tf % M, e = (tf / M) & 1, grp = tf / (2 * M);
+            v2f hp[P / 2];
+#pragma unroll
+            for (int p = 0; p < P / 2; p++) hp[p] = v2f{A.proto[r + (2 * p) * M], A.proto[r + (2 * p + 1) * M]};
+            const uint32_t rd = (uint32_t)((r + e * D + 16 * grp * M) * 8);                       // window start, bytes
+            // row of output i: 64 (grp / 2) + 16 (e + 2 (i & 1)) + 8 (grp & 1) + i / 2  (phase-major rows, see the FFT waves)
+            const uint32_t wr = PHASE_MAJOR ? (uint32_t)(((64 * (grp >> 1) + 16 * e + 8 * (grp & 1)) * ROW + r) * 8)
+                                            : (uint32_t)(((e + 32 * grp) * ROW + r) * 8);
+            auto fir_tile = [&](auto bufc) {
+                constexpr int BUF = decltype(bufc)::value;
+                const uint32_t a0 = (uint32_t)(uintptr_t)&xs[BUF][0] + rd;
+                char* uo = reinterpret_cast<char*>(&us[BUF][0]) + wr;
+                v2f wv[16 + P - 1];
+#pragma unroll
+                for (int q = 0; q < 19; q++)
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                               "+v"(wv[7]), "+v"(wv[8]), "+v"(wv[9]), "+v"(wv[10]), "+v"(wv[11]), "+v"(wv[12]),
+                               "+v"(wv[13]), "+v"(wv[14])
+                             :: "memory");
+                asm volatile("" : "+v"(wv[15]), "+v"(wv[16]), "+v"(wv[17]), "+v"(wv[18]) :: "memory");
+#pragma unroll
+                for (int i0 = 0; i0 < 16; i0 += 4) {
+                    if (i0 < 12) {
+#pragma unroll
+                        for (int q = i0 + 19; q < i0 + 23; q++)
+                            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+                    }
+                    v2f acc[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc[j]) : "v"(hp[0]), "v"(wv[i0 + j]));
+#pragma unroll
+                    for (int p = 1; p < P; p++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (p & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(wv[i0 + j + p]));
+                            else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(wv[i0 + j + p]));
+                        }
+                    }
+                    if (i0 < 12)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[i0 + 19]), "+v"(wv[i0 + 20]), "+v"(wv[i0 + 21]), "+v"(wv[i0 + 22]) :: "memory");
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = i0 + j;
+                        const int rowoff = PHASE_MAJOR ? (32 * (i & 1) + (i >> 1)) : 2 * i;
+                        *reinterpret_cast<float2*>(uo + rowoff * ROW * 8) = make_float2(acc[j].x, acc[j].y);
+                    }
+                }
+            };
+            lds_barrier();                                           // the staging waves' prologue
+            for (int it = 0; it < IT; it += 2) {
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {
+                    const int i2 = it + hb;
+                    if (i2 < IT) {
+                        if (i2 < NTL) {
+                            MF_STAMP(0);
+                            if (hb == 0) fir_tile(std::integral_constant<int, 0>{});
+                            else         fir_tile(std::integral_constant<int, 1>{});
+                            MF_STAMP(1);
+                        }
+                        lds_barrier();
+                        MF_STAMP(2);
+                    }
+                }
+            }
+        } else {
+            // =================================================================================
+            // Staging waves: the input span of tile i + 1 is in LDS before the barrier that ends tile i; its new
+            // samples were requested two tiles earlier into one of two register sets (a 2^24-sample-per-CU-second
+            // stream: the latency of a load under that traffic is about one tile time)
+            // =================================================================================
+            constexpr int NST = 64 * (kFirWaves - NFW);
+            const int ts = (w - NFW) * 64 + l;
+            auto load_pair = [&](uint64_t g) -> Raw {                  // samples g, g+1 (g even), zero past n
+                if (g + 1 < n) return iq_pair_raw<FMT>(x, g);
+                Raw v = Raw{};
+                if (g < n) v = iq_single_raw<FMT>(x, g);
+                return v;
+            };
+            constexpr int NPRE = (NEW / 2 + NST - 1) / NST, NOV = (OV / 2 + NST - 1) / NST;
+            Raw pre[2][NPRE];
+            auto fetch = [&](Raw (&set)[NPRE], uint32_t tile) {
+                const uint64_t in1 = (uint64_t)tile * NEW + OV;
+                if (in1 + NEW <= n) {
+#pragma unroll
+                    for (int k = 0; k < NPRE; k++)
+                        if (k * NST + NST <= NEW / 2 || ts + k * NST < NEW / 2) set[k] = iq_pair_raw<FMT>(x, in1 + 2ull * (uint64_t)(ts + k * NST));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPRE; k++)
+                        if (k * NST + NST <= NEW / 2 || ts + k * NST < NEW / 2) set[k] = load_pair(in1 + 2ull * (uint64_t)(ts + k * NST));
+                }
+            };
+            auto overlap = [&](int nb) {                                // xs[nb ^ 1][NEW ..] -> xs[nb][0 ..]
+                float4* dst = reinterpret_cast<float4*>(&xs[nb][0]);
+                const float4* src = reinterpret_cast<const float4*>(&xs[nb ^ 1][0]);
+#pragma unroll
+                for (int k = 0; k < NOV; k++)
+                    if (ts + k * NST < OV / 2) dst[ts + k * NST] = src[ts + k * NST + NEW / 2];
+            };
+            auto stage = [&](Raw (&set)[NPRE], int nb) {
+                float4* dst = reinterpret_cast<float4*>(&xs[nb][0]);
+#pragma unroll
+                for (int k = 0; k < NPRE; k++)
+                    if (k * NST + NST <= NEW / 2 || ts + k * NST < NEW / 2) dst[OV / 2 + ts + k * NST] = iq_pair_cvt<FMT>(set[k]);
+            };
+            {
+                float4* xb = reinterpret_cast<float4*>(&xs[0][0]);
+                const uint64_t in0 = (uint64_t)t_begin * NEW;
+                for (uint32_t q = (uint32_t)ts; q < (uint32_t)(SPAN / 2); q += NST) xb[q] = iq_pair_cvt<FMT>(load_pair(in0 + 2ull * q));
+                if (1 < NTL) fetch(pre[1], t_begin + 1u);
+            }
+            lds_barrier();
+            for (int it = 0; it < IT; it += 2) {
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {
+                    const int i2 = it + hb;
+                    if (i2 < IT) {
+                        if (i2 + 2 < NTL) fetch(pre[hb], t_begin + (uint32_t)i2 + 2u);
+                        if (i2 + 1 < NTL) { overlap(hb ^ 1); stage(pre[hb ^ 1], hb ^ 1); }
+                        MF_STAMP(0);
+                        lds_barrier();
+                        MF_STAMP(2);
+                    }
+                }
+            }
+        }
+    } else if (w < kFirWaves) {
         // =====================================================================================
         // FIR waves: stage the input span, run the FIR on the matrix pipe
         // =====================================================================================
@@ -510,19 +656,17 @@ extern "C" int snout_debug_mf_stamps(unsigned long long* out, uint32_t n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_stamps), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
 #endif
-int pfb_mfma_launch(uint32_t M, bool btle, int fmt, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
+int pfb_mfma_launch(uint32_t M, bool btle, int fmt, int impl, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
 {
-#define SNOUT_MF(MM, MODE)                                                                                 \
+#define SNOUT_MF(MM, MODE, IM)                                                                             \
     do {                                                                                                  \
-        if (fmt == kFmtSc8) hipLaunchKernelGGL((pfb_mfma<MM, MODE, kFmtSc8>), dim3(grid), dim3(mf::kThreads), 0, st, a);        \
-        else if (fmt == kFmtSc16) hipLaunchKernelGGL((pfb_mfma<MM, MODE, kFmtSc16>), dim3(grid), dim3(mf::kThreads), 0, st, a); \
-        else hipLaunchKernelGGL((pfb_mfma<MM, MODE, kFmtCf32>), dim3(grid), dim3(mf::kThreads), 0, st, a);                      \
+        if (fmt == kFmtSc8) hipLaunchKernelGGL((pfb_mfma<MM, MODE, kFmtSc8, IM>), dim3(grid), dim3(mf::kThreads), 0, st, a);        \
+        else if (fmt == kFmtSc16) hipLaunchKernelGGL((pfb_mfma<MM, MODE, kFmtSc16, IM>), dim3(grid), dim3(mf::kThreads), 0, st, a); \
+        else hipLaunchKernelGGL((pfb_mfma<MM, MODE, kFmtCf32, IM>), dim3(grid), dim3(mf::kThreads), 0, st, a);                      \
     } while (0)
-    if (M == 40) {
-        if (btle) SNOUT_MF(40, kMfBtle); else SNOUT_MF(40, kMfIq);
-    } else {
-        return SNOUT_EINVAL;
-    }
+    if (M != 40) return SNOUT_EINVAL;
+    if (impl == kFirMfma) { if (btle) SNOUT_MF(40, kMfBtle, kFirMfma); else SNOUT_MF(40, kMfIq, kFirMfma); }
+    else                  { if (btle) SNOUT_MF(40, kMfBtle, kFirValu); else SNOUT_MF(40, kMfIq, kFirValu); }
 #undef SNOUT_MF
     SNOUT_HIP(hipGetLastError());
     return 0;

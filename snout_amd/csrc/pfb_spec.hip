@@ -1,0 +1,476 @@
+// pfb_spec.hip — the M = 40 channelizer as ONE workgroup of specialised waves per CU (gfx950).
+//
+// Same arithmetic contract as pfb.hip / oracle/oracle_pfb.c (the channelizer replaces the one-channel hop of
+// snout/core/radio.py:415, snout/util/btle.py:62: SURVEY.md §8d cfg #3), other division of labour, decided by
+// what round 3 measured (profiles/r3_*):
+//   * f32 MFMA and VALU instructions of two waves on one SIMD do NOT issue side by side on gfx950
+//     (tools/coissue_probe.hip: both = the sum of each alone), so the FIR stays on the vector pipe as the packed-
+//     FMA sliding dot product of pfb.hip (the banded-Toeplitz matrix-pipe FIR of pfb_mfma.hip costs twice the
+//     cycles for its structural zeros and hides none of them);
+//   * pfb.hip's phases (FIR | FFT pass 3a | pass 3b) run in lock step with three barriers per tile, an LDS round
+//     trip inside the FFT, and five-wave workgroups that put two waves on one SIMD: ~49 % of the vector issue
+//     slots are used.  Here the FIR of tile i runs BESIDE the FFTs of tiles i-1 .. i-3 on other waves:
+//
+//   waves 0-4   FIR + staging: thread <-> (branch, output parity, group of 16 outputs) as in pfb.hip, 128 output
+//               times per tile, FIR outputs double-buffered in LDS; the same threads fetch the input two tiles
+//               ahead (two register sets) and stage it behind their FIR.
+//   waves 5-7, 9-11   FFT: a thread owns one output time of a 64-time block: 20 ds_read_b128 of its row, then
+//               the whole 8 x 5 FFT of oracle_pfb.c in registers (680 VALU, no LDS round trip, no barrier
+//               inside) and the epilogue on its 40 results; a block is spread over three tile times (two
+//               barriers inside the straight-line code), so six blocks are always in flight.
+//               BTLE: lane = 16 (m mod 4) + (m / 4 mod 16): y[m+4] is the next lane of the DPP row, and the 64
+//               lanes' hard bits of one channel come out of v_cmp as four 16-symbol pieces of its plane words;
+//               the last symbol of each piece needs the next block's first output times: those go through LDS.
+//   wave 8      idle (it only keeps the barriers' count).  Waves w, w + 4, w + 8 share a SIMD (cyclic placement),
+//               so SIMD 0 holds FIR waves 0 and 4, and the three SIMDs with ONE FIR wave hold two FFT waves
+//               each: 2 x 1024 against 1024 + 2 x 680 issue cycles per tile.  (Placement is for balance only.)
+//   One s_barrier per tile.
+#include "common.h"
+#include "iq_fmt.h"
+#include <type_traits>
+#include "pfb_tables.inc"
+
+namespace snout {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+// v_writelane_b32 as the compiler's own instruction (this clang has no __builtin_amdgcn_writelane): as inline asm
+// the hazard recogniser does not see it, and on gfx950 a VALU read of an SGPR needs two wait states behind the
+// v_cmp that wrote it.
+extern "C" __device__ int __llvm_amdgcn_writelane(int, int, int) __asm("llvm.amdgcn.writelane");
+
+#ifdef SNOUT_MF_STAMPS
+// Diagnostic build only (tools/mf_stamps.py): shader cycles each wave spends in its phases, summed over the tiles
+// of a workgroup: [block][wave][slot]; slot 7 = the wave's whole run, slot 6 = shader clock in kHz.
+__device__ unsigned long long g_sp_stamps[256 * 16 * 8];
+#define SP_STAMP(k)                                                              \
+    do {                                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();           \
+        st_acc[k] += now_ - st_last; st_last = now_;                             \
+    } while (0)
+#else
+#define SP_STAMP(k) do { } while (0)
+#endif
+
+namespace sp {
+
+struct cf { float re, im; };
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf cmul_tw(cf a, float c, float d)
+{
+    cf r;
+    r.re = __builtin_fmaf(a.re, c, -(a.im * d));
+    r.im = __builtin_fmaf(a.re, d, a.im * c);
+    return r;
+}
+__device__ __forceinline__ void dft4(const cf b[4], cf X[4])
+{
+    const cf s0 = cadd(b[0], b[2]), s1 = csub(b[0], b[2]);
+    const cf s2 = cadd(b[1], b[3]), s3 = csub(b[1], b[3]);
+    X[0] = cadd(s0, s2);
+    X[2] = csub(s0, s2);
+    X[1] = cf{s1.re + s3.im, s1.im - s3.re};
+    X[3] = cf{s1.re - s3.im, s1.im + s3.re};
+}
+__device__ __forceinline__ void dft8(const cf a[8], cf X[8])
+{
+    const float c = 0.70710678118654752440f;
+    const cf e[4] = {a[0], a[2], a[4], a[6]}, o[4] = {a[1], a[3], a[5], a[7]};
+    cf E[4], O[4], T[4];
+    dft4(e, E);
+    dft4(o, O);
+    T[0] = O[0];
+    T[1] = cf{(O[1].re + O[1].im) * c, (O[1].im - O[1].re) * c};
+    T[2] = cf{O[2].im, -O[2].re};
+    T[3] = cf{(O[3].im - O[3].re) * c, -((O[3].re + O[3].im) * c)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) { X[k] = cadd(E[k], T[k]); X[k + 4] = csub(E[k], T[k]); }
+}
+__device__ __forceinline__ void dft5(const cf b[5], cf X[5], const float C1, const float C2, const float S1, const float S2)
+{
+    const cf t1 = cadd(b[1], b[4]), t2 = cadd(b[2], b[3]), t3 = csub(b[1], b[4]), t4 = csub(b[2], b[3]);
+    cf a1, a2, s1, s2;
+    X[0] = cadd(cadd(b[0], t1), t2);
+    a1.re = __builtin_fmaf(C2, t2.re, __builtin_fmaf(C1, t1.re, b[0].re));
+    a1.im = __builtin_fmaf(C2, t2.im, __builtin_fmaf(C1, t1.im, b[0].im));
+    a2.re = __builtin_fmaf(C1, t2.re, __builtin_fmaf(C2, t1.re, b[0].re));
+    a2.im = __builtin_fmaf(C1, t2.im, __builtin_fmaf(C2, t1.im, b[0].im));
+    s1.re = __builtin_fmaf(S2, t4.re, S1 * t3.re);
+    s1.im = __builtin_fmaf(S2, t4.im, S1 * t3.im);
+    s2.re = __builtin_fmaf(-S1, t4.re, S2 * t3.re);
+    s2.im = __builtin_fmaf(-S1, t4.im, S2 * t3.im);
+    X[1] = cf{a1.re + s1.im, a1.im - s1.re};
+    X[4] = cf{a1.re - s1.im, a1.im + s1.re};
+    X[2] = cf{a2.re + s2.im, a2.im - s2.re};
+    X[3] = cf{a2.re - s2.im, a2.im + s2.re};
+}
+
+// Workgroup barrier that orders LDS traffic only (vector-memory loads and stores stay in flight).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Two wave layouts (W = waves per workgroup):
+//   12: waves 0-4 FIR (16 outputs per thread), 8 idle, 5-7 and 9-11 FFT   -- 3 waves per SIMD, <= 168 registers
+//   16: waves 0-9 FIR ( 8 outputs per thread), 10-15 FFT                  -- 4 waves per SIMD, <= 128 registers
+// Waves w, w + 4, w + 8, w + 12 share a SIMD: with 16 waves the SIMDs hold 3 FIR + 1 FFT, 3 + 1, 2 + 2, 2 + 2 waves =
+// 2216, 2216, 2384, 2384 issue cycles per tile (FIR wave 512, FFT wave 680), and a plain VALU stream reaches 81 % of its
+// peak at four waves per SIMD against 73 % at three (tools/fmabench.hip).
+constexpr int kFftWaves = 6;
+template <int W> struct Layout;
+template <> struct Layout<12> { static constexpr int FIR = 5, OUT = 16; };
+template <> struct Layout<16> { static constexpr int FIR = 10, OUT = 8; };
+
+}  // namespace sp
+
+// Output modes
+constexpr int kSpIq = 0, kSpBtle = 1;
+
+template <int MODE, int FMT, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W / 4, W / 4)))
+void pfb_spec40(const PfbMfArgs A)
+{
+    using namespace sp;
+    constexpr int kFirWaves = Layout<W>::FIR, OUT = Layout<W>::OUT, NG = 64 / OUT;    // NG groups of OUT outputs per (branch, parity) and tile
+    constexpr int M = 40, T = 128, M1 = 8, M2 = 5, ROW = 42, D = M / 2, P = 16;
+    constexpr int SPAN = (T - 1) * D + M * P, NEW = T * D, OV = SPAN - NEW;
+    constexpr int NST = 64 * kFirWaves;                 // threads that compute the FIR and stage
+    static_assert(NST == 2 * M * NG && (NEW / 2) % NST == 0 && OV / 2 <= NST, "FIR / staging thread map");
+    constexpr bool BT = MODE == kSpBtle;
+
+    __shared__ float2 xs[2][SPAN];
+    __shared__ float2 us[2][T * ROW];
+    __shared__ float2 cfirst[BT ? kFftWaves : 1][2][BT ? M * 4 : 1];    // [wave][block parity][channel][phase]: y of the block's first four times
+    __shared__ float2 clast[BT ? kFftWaves : 1][BT ? M * 4 : 1];        // ... of its last four
+
+    const uint32_t seg = blockIdx.x / A.segs.wgs_per_seg, bid = blockIdx.x - seg * A.segs.wgs_per_seg;
+    const void* __restrict__ x = A.segs.x[seg];
+    uint16_t* planes16 = A.planes16 ? A.planes16 + (uint64_t)seg * A.segs.planes_seg : nullptr;
+    const uint64_t n = A.n, n_out = A.n_out;
+    const uint32_t n_tiles = A.n_tiles;
+
+    const uint32_t t_begin = bid * A.tiles_per_wg;
+    uint32_t t_end = t_begin + A.tiles_per_wg;
+    if (t_end > n_tiles) t_end = n_tiles;
+    if (t_begin >= t_end) return;
+    // BTLE: the first four output times of the tile behind the range complete the range's last symbols
+    const uint32_t t_stop = (BT && t_end < n_tiles) ? t_end + 1u : t_end;
+    const int NTL = (int)(t_stop - t_begin);            // tiles this workgroup computes
+    const int IT = NTL + 4;                              // barriers after the first one (pipeline drain included)
+
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+#ifdef SNOUT_MF_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    if (w < kFirWaves) {
+        // =====================================================================================
+        // FIR + staging waves: thread <-> (branch r, output parity e, group grp): the 16 outputs
+        // m = e + 2 (16 grp + i) of one branch are a sliding dot product over z[q] = x[r + e D + q M]
+        // =====================================================================================
+        using Raw = typename IqRaw<FMT>::pair;
+        const int tf = w * 64 + l, r = tf % M, e = (tf / M) & 1, grp = tf / (2 * M);
+        v2f hp[P / 2];
+#pragma unroll
+        for (int p = 0; p < P / 2; p++) hp[p] = v2f{A.proto[r + (2 * p) * M], A.proto[r + (2 * p + 1) * M]};
+        const uint32_t rd = (uint32_t)((r + e * D + OUT * grp * M) * 8);                      // window start, bytes
+        // row of output m = e + 2 (OUT grp + i), rows in the FFT waves' lane order (64 (m / 64) + 16 (m mod 4) + (m mod 64) / 4):
+        //   OUT = 16: 64 (grp / 2) + 16 (e + 2 (i & 1)) + 8 (grp & 1) + i / 2;   OUT = 8: 64 (grp / 4) + 16 (e + 2 (i & 1)) + 4 (grp & 3) + i / 2
+        const uint32_t wr = OUT == 16 ? (uint32_t)(((64 * (grp >> 1) + 16 * e + 8 * (grp & 1)) * ROW + r) * 8)
+                                      : (uint32_t)(((64 * (grp >> 2) + 16 * e + 4 * (grp & 3)) * ROW + r) * 8);
+
+        auto load_pair = [&](uint64_t g) -> Raw {                  // samples g, g+1 (g even), zero past n
+            if (g + 1 < n) return iq_pair_raw<FMT>(x, g);
+            Raw v = Raw{};
+            if (g < n) v = iq_single_raw<FMT>(x, g);
+            return v;
+        };
+        constexpr int NPRE = NEW / 2 / NST;                         // 4 new pairs per thread and tile
+        Raw pre[2][NPRE];
+        auto fetch = [&](Raw (&set)[NPRE], uint32_t tile) {
+            const uint64_t in1 = (uint64_t)tile * NEW + OV;
+            if (in1 + NEW <= n) {
+#pragma unroll
+                for (int k = 0; k < NPRE; k++) set[k] = iq_pair_raw<FMT>(x, in1 + 2ull * (uint64_t)(tf + k * NST));
+            } else {
+#pragma unroll
+                for (int k = 0; k < NPRE; k++) set[k] = load_pair(in1 + 2ull * (uint64_t)(tf + k * NST));
+            }
+        };
+        auto stage = [&](Raw (&set)[NPRE], int nb) {                // xs[nb]: overlap from xs[nb ^ 1], new samples from the set
+            float4* dst = reinterpret_cast<float4*>(&xs[nb][0]);
+            const float4* src = reinterpret_cast<const float4*>(&xs[nb ^ 1][0]);
+            if (tf < OV / 2) dst[tf] = src[tf + NEW / 2];
+#pragma unroll
+            for (int k = 0; k < NPRE; k++) dst[OV / 2 + tf + k * NST] = iq_pair_cvt<FMT>(set[k]);
+        };
+        auto fir_tile = [&](auto bufc) {
+            constexpr int BUF = decltype(bufc)::value;
+            const uint32_t a0 = (uint32_t)(uintptr_t)&xs[BUF][0] + rd;
+            char* uo = reinterpret_cast<char*>(&us[BUF][0]) + wr;
+            // OUT outputs from one window of OUT + 15 samples: the first four outputs need samples 0..18, every further
+            // four outputs four more, read while the four before them are computed
+            v2f wv[OUT + P - 1];
+#pragma unroll
+            for (int q = 0; q < 19; q++)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                           "+v"(wv[7]), "+v"(wv[8]), "+v"(wv[9]), "+v"(wv[10]), "+v"(wv[11]), "+v"(wv[12]),
+                           "+v"(wv[13]), "+v"(wv[14])
+                         :: "memory");
+            asm volatile("" : "+v"(wv[15]), "+v"(wv[16]), "+v"(wv[17]), "+v"(wv[18]) :: "memory");
+#pragma unroll
+            for (int i0 = 0; i0 < OUT; i0 += 4) {
+                if (i0 < OUT - 4) {
+#pragma unroll
+                    for (int q = i0 + 19; q < i0 + 23; q++)
+                        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
+                }
+                v2f acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc[j]) : "v"(hp[0]), "v"(wv[i0 + j]));
+#pragma unroll
+                for (int p = 1; p < P; p++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (p & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(wv[i0 + j + p]));
+                        else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[j]) : "v"(hp[p >> 1]), "v"(wv[i0 + j + p]));
+                    }
+                }
+                if (i0 < OUT - 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[i0 + 19]), "+v"(wv[i0 + 20]), "+v"(wv[i0 + 21]), "+v"(wv[i0 + 22]) :: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = i0 + j;
+                    *reinterpret_cast<float2*>(uo + (32 * (i & 1) + (i >> 1)) * ROW * 8) = make_float2(acc[j].x, acc[j].y);
+                }
+            }
+        };
+        // ---- prologue: the whole span of the first tile; the second tile's new samples requested
+        {
+            float4* xb = reinterpret_cast<float4*>(&xs[0][0]);
+            const uint64_t in0 = (uint64_t)t_begin * NEW;
+            for (uint32_t q = (uint32_t)tf; q < (uint32_t)(SPAN / 2); q += NST) xb[q] = iq_pair_cvt<FMT>(load_pair(in0 + 2ull * q));
+            if (1 < NTL) fetch(pre[1], t_begin + 1u);
+        }
+        lds_barrier();
+        for (int it = 0; it < IT; it += 2) {
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+                const int i2 = it + hb;
+                if (i2 < IT) {
+                    if (i2 < NTL) {
+                        // tile i2 + 2's samples: two tiles ahead into the set tile i2's came from; tile i2 + 1's (requested
+                        // one tile ago) go to LDS behind this tile's FIR: a load has one tile time + the FIR to arrive
+                        if (i2 + 2 < NTL) fetch(pre[hb], t_begin + (uint32_t)i2 + 2u);
+                        SP_STAMP(0);
+                        if (hb == 0) fir_tile(std::integral_constant<int, 0>{});
+                        else         fir_tile(std::integral_constant<int, 1>{});
+                        SP_STAMP(1);
+                        if (i2 + 1 < NTL) stage(pre[hb ^ 1], hb ^ 1);
+                        SP_STAMP(4);
+                    }
+                    lds_barrier();
+                    SP_STAMP(2);
+                }
+            }
+        }
+    } else if (W == 12 && w == 8) {
+        // wave 8 shares its SIMD with FIR waves 0 and 4: it stays idle and only keeps the barriers' count
+        for (int i = 0; i < IT + 1; i++) lds_barrier();
+    } else {
+        // =====================================================================================
+        // FFT waves: a thread owns one output time of a 64-time block
+        // =====================================================================================
+        // Wave f takes the blocks b = f + 6 k (block b = 64-time half b & 1 of tile b >> 1): tile j = f / 2 + 3 k, half
+        // f & 1; a block takes three tile times: Q1 (row, first stage) | barrier | Q2 | barrier | Q3 | barrier.
+        const int f = W == 12 ? (w < 8 ? w - kFirWaves : w - kFirWaves - 1) : w - kFirWaves, j0 = f >> 1, half = f & 1;
+        // The FFT is dependency chains; the FIR waves' 256 independent packed FMAs per tile are always ready and, being the
+        // older waves, would win every arbitration: FFT waves issue first (priority, then age), the FIR fills their gaps.
+#ifndef SNOUT_SP_PRIO_FFT
+#define SNOUT_SP_PRIO_FFT 2
+#endif
+        __builtin_amdgcn_s_setprio(SNOUT_SP_PRIO_FFT);
+        const float* const tw = kTw40;
+        const float c5_1 = kTw5[2], c5_2 = kTw5[4], s5_1 = -kTw5[3], s5_2 = -kTw5[5];
+        const uint32_t mloc = 4u * (uint32_t)(l & 15) + (uint32_t)(l >> 4);      // output time of this lane within its block
+        int itc = 0;
+#ifdef SNOUT_MF_STAMPS
+        auto bar = [&]() { SP_STAMP(3); lds_barrier(); itc++; SP_STAMP(2); };
+#else
+        auto bar = [&]() { lds_barrier(); itc++; };
+#endif
+        bar();                                                       // the FIR waves' prologue
+        for (int i = 0; i <= j0; i++) bar();                         // barrier j + 2 ends tile j's FIR
+
+        // BTLE: state of the block whose last symbols wait for the next block's first output times.
+        // Lane k < 40 holds the 64 hard bits of channel k.
+        uint32_t pm_lo = 0, pm_hi = 0;
+        uint64_t pend_m0 = 0;
+        int pend_par = 0;
+        bool pending = false;
+        auto finalize = [&]() {
+            if constexpr (BT) {
+                if (pending && l < M) {
+                    const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;           // bits exist for m < n_out - 4
+                    // the block behind this one is the next wave's (wave 0's NEXT block behind wave 5's)
+                    const int fs = f == kFftWaves - 1 ? 0 : f + 1;
+                    const int spar = f == kFftWaves - 1 ? pend_par ^ 1 : pend_par;
+                    const float4* la = reinterpret_cast<const float4*>(&clast[f][l * 4]);
+                    const float4* fi = reinterpret_cast<const float4*>(&cfirst[fs][spar][l * 4]);
+                    const float4 l01 = la[0], l23 = la[1], f01 = fi[0], f23 = fi[1];
+                    const uint32_t b0 = (l01.x * f01.y) > (f01.x * l01.y) ? 1u : 0u;
+                    const uint32_t b1 = (l01.z * f01.w) > (f01.z * l01.w) ? 1u : 0u;
+                    const uint32_t b2 = (l23.x * f23.y) > (f23.x * l23.y) ? 1u : 0u;
+                    const uint32_t b3 = (l23.z * f23.w) > (f23.z * l23.w) ? 1u : 0u;
+                    const uint32_t lo = (pm_lo & 0x7FFF7FFFu) | (b0 << 15) | (b1 << 31);
+                    const uint32_t hi = (pm_hi & 0x7FFF7FFFu) | (b2 << 15) | (b3 << 31);
+                    // symbols whose sample exists: m0 + 4 sy + j < nbits, a prefix of the 16 per phase
+                    const uint32_t left = nbits > pend_m0 ? (uint32_t)(nbits - pend_m0 < 64u ? nbits - pend_m0 : 64u) : 0u;
+                    uint16_t* dst = planes16 + ((uint64_t)l * A.plane_stride + (pend_m0 >> 8) * 4u) * 4u + (uint32_t)((pend_m0 & 255u) >> 6);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t cnt = left > (uint32_t)j ? (left - (uint32_t)j + 3u) >> 2 : 0u;     // <= 16
+                        const uint32_t v = ((j < 2 ? lo : hi) >> (16 * (j & 1))) & 0xFFFFu;
+                        dst[4 * j] = (uint16_t)(v & ((1u << cnt) - 1u));
+                    }
+                }
+                pending = false;
+            }
+        };
+
+        int kblk = 0;
+        for (int j = j0; j < NTL; j += 3, kblk++) {
+            const uint32_t tile = t_begin + (uint32_t)j;
+            const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)half;
+            const bool emit = tile < t_end;                          // the tile behind the range only supplies its first four times
+            const bool need = emit || half == 0;
+            const int par = kblk & 1;
+            // ---- Q1: the row, 8-point DFTs over n1 and the twiddles W_40^{n2 k1}
+            cf Bv[M2][M1];
+            if (need) {
+                const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
+                cf u[M];
+#pragma unroll
+                for (int q = 0; q < M / 2; q++) {
+                    const float4 v = rowp[q];
+                    u[2 * q] = cf{v.x, v.y};
+                    u[2 * q + 1] = cf{v.z, v.w};
+                }
+#pragma unroll
+                for (int n2 = 0; n2 < M2; n2++) {
+                    cf a[M1], X[M1];
+#pragma unroll
+                    for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
+                    dft8(a, X);
+#pragma unroll
+                    for (int k1 = 0; k1 < M1; k1++) {
+                        const int jj = (n2 * k1) % M;
+                        Bv[n2][k1] = jj == 0 ? X[k1] : cmul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
+                    }
+                }
+            }
+            bar();
+            // ---- Q2, Q3: 5-point DFTs over n2 per k1, epilogue per channel k = k1 + 8 k2
+            finalize();                       // the block before this one: its successor's first output times are there now
+            uint32_t m_lo = 0, m_hi = 0;
+            auto do_k1 = [&](int k1) {
+                cf b[M2], Y[M2];
+#pragma unroll
+                for (int n2 = 0; n2 < M2; n2++) b[n2] = Bv[n2][k1];
+                dft5(b, Y, c5_1, c5_2, s5_1, s5_2);
+                if constexpr (BT) {
+                    // bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m]); m + 4 is the next lane of the 16-lane row.  The
+                    // factor (-1)^{km} is the same for m and m + 4 and cancels in both products.
+#pragma unroll
+                    for (int k2 = 0; k2 < M2; k2++) {
+                        const int k = k1 + M1 * k2;
+                        const float qn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].im), 0x101, 0xF, 0xF, true));
+                        const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].re), 0x101, 0xF, 0xF, true));
+                        const uint64_t mk = __builtin_amdgcn_ballot_w64((Y[k2].re * qn) > (in * Y[k2].im));
+                        m_lo = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)mk, k, (int)m_lo);
+                        m_hi = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)(mk >> 32), k, (int)m_hi);
+                    }
+                    const int li = l & 15;
+                    if (li == 0) {                                   // first four output times of the block
+#pragma unroll
+                        for (int k2 = 0; k2 < M2; k2++) cfirst[f][par][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
+                    } else if (li == 15) {                           // last four
+#pragma unroll
+                        for (int k2 = 0; k2 < M2; k2++) clast[f][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
+                    }
+                } else {
+                    const uint64_t mg = m0b + mloc;
+                    if (mg < n_out) {
+#pragma unroll
+                        for (int k2 = 0; k2 < M2; k2++) {
+                            const int k = k1 + M1 * k2;
+                            cf v = Y[k2];
+                            if ((k & 1) && (mg & 1)) { v.re = -v.re; v.im = -v.im; }
+                            A.y[(uint64_t)k * A.y_stride + mg] = make_float2(v.re, v.im);
+                        }
+                    }
+                }
+            };
+            if (need) {
+#pragma unroll
+                for (int k1 = 0; k1 < M1 / 2; k1++) do_k1(k1);
+            }
+            bar();
+            if (need) {
+#pragma unroll
+                for (int k1 = M1 / 2; k1 < M1; k1++) do_k1(k1);
+                if constexpr (BT) {
+                    pm_lo = m_lo; pm_hi = m_hi; pend_m0 = m0b; pend_par = par; pending = emit;
+                }
+            }
+            bar();
+        }
+        // ---- drain: the block behind the last one is finished one barrier later; then keep step with the FIR waves
+        if (itc < IT + 1) bar();
+        finalize();
+        while (itc < IT + 1) bar();
+    }
+#ifdef SNOUT_MF_STAMPS
+    if (l == 0 && blockIdx.x < 256) {
+        st_acc[7] = __builtin_amdgcn_s_memtime() - st_t0;
+        st_acc[6] = st_acc[7] * 100000ull / (__builtin_amdgcn_s_memrealtime() - st_r0 + 1ull);
+        for (int k = 0; k < 8; k++) g_sp_stamps[(blockIdx.x * 16 + w) * 8 + k] = st_acc[k];
+    }
+#endif
+}
+
+// =============================================================================================
+// Host side
+// =============================================================================================
+#ifdef SNOUT_MF_STAMPS
+extern "C" int snout_debug_sp_stamps(unsigned long long* out, uint32_t n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_stamps), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+}
+#endif
+
+int pfb_spec_launch(uint32_t M, bool btle, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
+{
+#define SNOUT_SP(MODE, WW)                                                                                 \
+    do {                                                                                                  \
+        if (fmt == kFmtSc8) hipLaunchKernelGGL((pfb_spec40<MODE, kFmtSc8, WW>), dim3(grid), dim3(64 * WW), 0, st, a);        \
+        else if (fmt == kFmtSc16) hipLaunchKernelGGL((pfb_spec40<MODE, kFmtSc16, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
+        else hipLaunchKernelGGL((pfb_spec40<MODE, kFmtCf32, WW>), dim3(grid), dim3(64 * WW), 0, st, a);                      \
+    } while (0)
+    if (M != 40) return SNOUT_EINVAL;
+    if (waves == 12) { if (btle) SNOUT_SP(kSpBtle, 12); else SNOUT_SP(kSpIq, 12); }
+    else             { if (btle) SNOUT_SP(kSpBtle, 16); else SNOUT_SP(kSpIq, 16); }
+#undef SNOUT_SP
+    SNOUT_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace snout

@@ -25,14 +25,16 @@ for _ in range(3):
 k = rx.profile_history()[-3:]
 lib = _ffi.load()
 buf = np.zeros(256 * 16 * 8, dtype=np.uint64)
-rc = lib.snout_debug_mf_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(buf.size))
+fn = lib.snout_debug_mf_stamps if os.environ.get('SNOUT_PFB_IMPL', 'spec') in ('mfma', 'spec16') else lib.snout_debug_sp_stamps
+rc = fn(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(buf.size))
 assert rc == 0
 s = buf.reshape(256, 16, 8).astype(np.float64)
 tiles = (n - 640) // 20 // 128 / 256.0
 print(f"n={n:.3g} kernel {k.mean():.3f} ms, {tiles:.0f} tiles per workgroup, clock {np.median(s[:, :, 6]) / 1e6:.2f} GHz")
 fir, fft = s[:, :8, :], s[:, 8:, :]
 med = lambda a: float(np.median(a)) / tiles
+print("(front-end waves 0-7: FIR = slots 0 1 2 = before / in / after the FIR; staging waves: slot 0 = fetch+stage incl. load wait, 2 = barrier)")
 print(f"FIR waves, cycles per tile: stage+fetch {med(fir[:, :, 0]):.0f}  mfma chains {med(fir[:, :, 1]):.0f}  barrier {med(fir[:, :, 2]):.0f}  total {med(fir[:, :, 7]):.0f}")
 print(f"FFT waves, cycles per tile: work {med(fft[:, :, 3]):.0f}  barrier {med(fft[:, :, 2]):.0f}  total {med(fft[:, :, 7]):.0f}")
 for w in range(16):
-    print(f"  wave {w:2d}: " + " ".join(f"{float(np.median(s[:, w, j])) / tiles:7.0f}" for j in (0, 1, 2, 3, 7)))
+    print(f"  wave {w:2d}: " + " ".join(f"{float(np.median(s[:, w, j])) / tiles:7.0f}" for j in (0, 1, 4, 2, 3, 7)))

@@ -16,7 +16,8 @@ for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   ( /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize $defs -c pfb.hip -o "$OUT/obj/pfb_$name.o" &&
     /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize $defs -c pfb_mfma.hip -o "$OUT/obj/pfb_mfma_$name.o" &&
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libsnout_rx_$name.so" "$OUT/obj/pfb_$name.o" "$OUT/obj/pfb_mfma_$name.o" \
+    /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize $defs -c pfb_spec.hip -o "$OUT/obj/pfb_spec_$name.o" &&
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libsnout_rx_$name.so" "$OUT/obj/pfb_$name.o" "$OUT/obj/pfb_mfma_$name.o" "$OUT/obj/pfb_spec_$name.o" \
       "$OUT/obj/btle.o" "$OUT/obj/zigbee.o" "$OUT/obj/membench.o" "$OUT/obj/records.o" "$OUT/obj/formats.o" "$OUT/obj/snout_rx.o" && echo "built $name [$defs]" ) &
 done
 wait
