@@ -185,8 +185,10 @@ class AsyncRecordGather:
     (synchronous) all_gather and raise the capacity for the exchanges that follow -- overflow is a
     collective decision, never one rank raising while the others sit in the collective.
 
-    ``width`` < 160 gathers only the first ``width`` bytes of each record (BTLE records use at most
-    24 + 42 bytes; the rest is zero by construction); a record that does not fit is a ValueError.
+    ``width`` < 160 gathers only the first ``width`` bytes of each record (a BTLE record is at most 24 + 2 + 63 + 3
+    bytes: 96 holds every record the decoder can emit, also a false access-address match with a 6-bit length on a
+    data channel; the rest is zero by construction).  A record that does not fit is a ValueError -- like the
+    overflow a collective one: its length travels in the header slot and every rank raises in ``finish()``.
     """
 
     def __init__(self, device=None, group=None, width: int = REC, dedup_tol: Optional[int] = None,
@@ -198,6 +200,9 @@ class AsyncRecordGather:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        # with a process group the exchange is a real collective even at world size 1 (a one-GPU box then runs the
+        # RCCL all_gather path that N > 1 runs); without one it is a device copy
+        self.collective = dist.is_initialized()
         self.on_gpu = self.backend == "nccl" or (self.backend == "none" and device is not None
                                                  and torch.device(device).type == "cuda")
         self.device = torch.device(device) if self.on_gpu else torch.device("cpu")
@@ -227,12 +232,13 @@ class AsyncRecordGather:
             n_host = torch.zeros(1, dtype=torch.int64, pin_memory=pin)
         ev = torch.cuda.Event() if self.on_gpu else None
         up = torch.cuda.Event() if self.on_gpu else None
-        return dict(cap=cap, send=send, recv=recv, hdr=hdr, host=host, n_host=n_host, ev=ev, up=up,
-                    fill=0, n=0, rest=[])
+        wide = torch.zeros(self.world, dtype=torch.int64, pin_memory=pin)
+        return dict(cap=cap, send=send, recv=recv, hdr=hdr, whdr=wide, host=host, n_host=n_host, ev=ev, up=up,
+                    fill=0, n=0, rest=[], wide=0)
 
     def _agree(self, n: int) -> int:
         t = self.torch.tensor([n], dtype=self.torch.int64, device=self.device)
-        if self.world > 1:
+        if self.collective:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
@@ -254,7 +260,7 @@ class AsyncRecordGather:
         if self.slots[k] is None or self.slots[k]["cap"] < self.cap:
             self.slots[k] = self._make_slot(self.cap)
         slot = self.slots[k]
-        slot["fill"], slot["n"], slot["rest"] = 0, 0, []
+        slot["fill"], slot["n"], slot["rest"], slot["wide"] = 0, 0, [], 0
         self.cur = slot
 
     def append(self, rec: np.ndarray, dev_ptr: int = 0, own_from: int = 0, rx=None) -> None:
@@ -268,8 +274,9 @@ class AsyncRecordGather:
         n = int(rec.size)
         if n == 0:
             return
-        if int(rec["len"].max()) > self.width - 24:
-            raise ValueError(f"record of {int(rec['len'].max())} bytes does not fit the {self.width}-byte wire format")
+        # a record longer than the wire format holds: NOT an exception here (the other ranks would sit in the
+        # all_gather): its length travels in the header slot and every rank raises together in finish()
+        slot["wide"] = max(slot["wide"], int(rec["len"].max()))
         W = self.width
         slot["n"] += n
         take = min(n, slot["cap"] - slot["fill"])
@@ -309,16 +316,18 @@ class AsyncRecordGather:
         with self._ctx():
             hdr = np.zeros(W, dtype=np.uint8)
             hdr[:8] = np.frombuffer(np.uint64(slot["n"]).tobytes(), dtype=np.uint8)
+            hdr[8:16] = np.frombuffer(np.uint64(slot["wide"]).tobytes(), dtype=np.uint8)      # longest record appended
             slot["send"][:W].copy_(torch.from_numpy(hdr), non_blocking=True)
             if self.on_gpu:
                 slot["up"].record(self.stream)       # the callers' record buffers may be reused after this
-            if self.world > 1:
+            if self.collective:
                 self.dist.all_gather_into_tensor(slot["recv"], slot["send"], group=self.group)
             else:
                 slot["recv"].copy_(slot["send"])
             blocks = slot["recv"].view(self.world, (cap + 1) * W)
             counts = blocks[:, :8].contiguous().view(torch.int64).reshape(self.world)
             slot["hdr"].copy_(counts, non_blocking=True)         # every rank learns every count
+            slot["whdr"].copy_(blocks[:, 8:16].contiguous().view(torch.int64).reshape(self.world), non_blocking=True)
             if self.rank == 0:
                 if self.dedup_tol is not None:
                     rows = blocks[:, W:].reshape(self.world * cap, W).view(torch.int64)
@@ -357,7 +366,7 @@ class AsyncRecordGather:
             send[:mine.size * W] = torch.from_numpy(raw.copy().reshape(-1))
         send = send.to(self.device)
         recv = torch.zeros(self.world * over * W, dtype=torch.uint8, device=self.device)
-        if self.world > 1:
+        if self.collective:
             self.dist.all_gather_into_tensor(recv, send, group=self.group)
         else:
             recv.copy_(send)
@@ -381,6 +390,9 @@ class AsyncRecordGather:
             slot["ev"].synchronize()
         W, cap = self.width, slot["cap"]
         counts = [int(c) for c in slot["hdr"].numpy()]
+        widest = int(slot["whdr"].numpy().max())
+        if widest > W - 24:             # every rank sees the same headers: every rank raises, none is left in a collective
+            raise ValueError(f"a rank appended a record of {widest} bytes: it does not fit the {W}-byte wire format")
         rest = self._exchange_rest(slot, counts) if max(counts) > cap else None
         if self.rank != 0:
             return None

@@ -85,7 +85,10 @@ class ShardedScan:
                           for j in range(len(self._segs))]
         self._source = source
         self._sink = sink
-        self._appended = [None] * len(self.rxs)     # event behind the last device-side append of each handle
+        # event behind the last device-side append of each handle: kept across start() -- the previous scan's last
+        # pack kernels may still be reading the result slots this scan's first submits reuse
+        if getattr(self, "_appended", None) is None or len(self._appended) != len(self.rxs):
+            self._appended = [None] * len(self.rxs)
         # submissions: runs of up to `batch` consecutive segments of equal length
         self._subs = sdist.group_submissions(self._segs, self.batch)
         self._next = 0                  # next submission

@@ -257,9 +257,53 @@ def test_device_dedup_equals_host_dedup():
 
 
 def test_gather_rejects_records_wider_than_the_wire_format():
+    """Too wide for the wire: not an exception in append() (other ranks would sit in the all_gather) but a
+    collective one -- the length travels in the header slot and finish() raises."""
     g = sdist.AsyncRecordGather(width=80)
     r = _recs([(1, 11, 5)])
     r["len"] = 100
     g.begin(1)
+    g.append(r)
+    g.launch()
     with pytest.raises(ValueError):
-        g.append(r)
+        g.finish()
+
+
+def _worker_wide(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sdist.AsyncRecordGather(width=80)
+        r = _recs([(0, 3 + rank, 1000 + i) for i in range(5)])
+        if rank == 1:
+            r["len"][2] = 68            # a false access-address match on a data channel: 2 + 63 + 3 bytes
+        g.start(r)
+        try:
+            g.finish()
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "ValueError"))
+        dist.barrier()                  # both ranks are still in step: neither hangs in a collective
+    finally:
+        dist.destroy_process_group()
+
+
+def test_too_wide_record_on_one_rank_raises_on_every_rank_gloo_world2():
+    """only rank 1 holds the oversized record; both ranks must raise, in finish()."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_wide, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == {0: "ValueError", 1: "ValueError"}
