@@ -51,9 +51,9 @@ PFB_FLOP = {40: (40 * 16 * 4 + 5 * 40 * np.log2(40)) / 20, 16: (16 * 16 * 4 + 5 
 
 WORKLOADS = {
     # name: (proto, n_channels, channel, samples per GPU, gathered record bytes, description)
-    "cfg2": (0, 1, 37, 1e9, 80,
+    "cfg2": (0, 1, 37, 1e9, 96,
              "cfg2: single-channel BTLE (ch37) GFSK demod + access-address correlate + dewhiten/CRC"),
-    "cfg3": (0, 40, 0, 8e8, 80,
+    "cfg3": (0, 40, 0, 8e8, 96,
              "cfg3: 80 Msps wideband -> 40-channel polyphase channelizer -> BTLE receive on every channel"),
     "cfg4": (1, 16, 0, 3.2e8, 160,
              "cfg4: 32 Msps wideband -> 16-channel polyphase channelizer -> 802.15.4 receive on every channel"),
@@ -165,7 +165,7 @@ def cpu_leg(host: np.ndarray, workload: str, threads: int, passes: int):
         best = dt if best is None else min(best, dt)
         n_pk = len(pk)
     oracle_py.set_threads(1)
-    return best, n_pk
+    return best, n_pk, pk
 
 
 def cpu_baseline(x_dev, workload: str, n_sample: int):
@@ -177,8 +177,8 @@ def cpu_baseline(x_dev, workload: str, n_sample: int):
     if host.dtype != np.float32:
         host = oracle_py.from_int(host)     # the oracle's definition of integer input (untimed)
     ncores = oracle_py.hw_threads()
-    t1, n_pk = cpu_leg(host, workload, 1, passes=2)
-    tall, n_pk_all = cpu_leg(host, workload, ncores, passes=3)
+    t1, n_pk, pk1 = cpu_leg(host, workload, 1, passes=2)
+    tall, n_pk_all, _ = cpu_leg(host, workload, ncores, passes=3)
     if workload in ("cfg2", "cfg3"):        # BTLE: the seams lose nothing (802.15.4 segments restart the DC filter)
         assert abs(n_pk - n_pk_all) <= max(4, n_pk // 50), (n_pk, n_pk_all)
     return {"value": n_sample / t1 / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
@@ -187,14 +187,60 @@ def cpu_baseline(x_dev, workload: str, n_sample: int):
             "all_cores": {"value": n_sample / tall / 1e6, "unit": "Msamples/s", "cores": ncores,
                           "how": "same oracle, one OpenMP task per overlapping segment (~4 per thread), each the "
                                  "whole serial chain over every channel; best of 3 passes"},
-            "nproc": os.cpu_count(), "cpu_model": cpu_model(), "packets_in_sample": int(n_pk)}
+            "nproc": os.cpu_count(), "cpu_model": cpu_model(), "packets_in_sample": int(n_pk)}, pk1
+
+
+# ------------------------------------------------------------------------------------------------
+# parity in the same run: the HIP path and the oracle on the same prefix of the capture
+# ------------------------------------------------------------------------------------------------
+PARITY_FIELDS = ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags")
+
+
+def oracle_records(x_dev, workload: str, n_sample: int):
+    """The oracle's records for the first n_sample samples, as ONE segment (all host threads inside the
+    channelizer / across the bins: same records as with one thread, sooner)."""
+    from oracle import oracle_py
+    host = x_dev[:2 * n_sample].cpu().numpy()
+    if host.dtype != np.float32:
+        host = oracle_py.from_int(host)
+    oracle_py.set_threads(oracle_py.hw_threads())
+    try:
+        if workload == "cfg2":
+            return oracle_py.btle_segment(host, channel=37, cap=max(1024, host.size // 4096))[0]
+        if workload == "zigbee1":
+            return oracle_py.zigbee_segment(host, channel=11)
+        return oracle_py.wideband_segment(host, proto=0 if workload == "cfg3" else 1)
+    finally:
+        oracle_py.set_threads(1)
+
+
+def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=None):
+    """What the reference's consumer keeps are the decoded records (snout/core/message.py:226 keeps the CRC0
+    lines): the GPU's record set on the prefix must EQUAL the oracle's -- every field and every byte."""
+    from snout_amd.rx import SnoutRx
+    proto, n_ch, channel = WORKLOADS[workload][:3]
+    if want is None:
+        want = oracle_records(x_dev, workload, n_sample)
+    with SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt) as rx:
+        got = rx.process(x_dev[:2 * n_sample]).copy()
+
+    def canon(r):
+        return r[np.lexsort((r["len"], r["sample_index"], r["channel"]))]
+    equal = len(got) == len(want)
+    if equal:
+        a, b = canon(got), canon(want)
+        equal = all(np.array_equal(a[f], b[f]) for f in PARITY_FIELDS) and np.array_equal(a["bytes"], b["bytes"])
+    assert equal, f"{workload}: the GPU's records on the first {n_sample} samples differ from the oracle's ({len(got)} vs {len(want)})"
+    return {"workload": workload, "samples": int(n_sample), "records": int(len(want)),
+            "crc_ok_records": int(want["crc_ok"].sum()), "equal": True,
+            "compared": "every record field and byte, set equality after sorting by (channel, sample_index), against the CPU oracle"}
 
 
 # ------------------------------------------------------------------------------------------------
 # one workload on one handle, pipelined submit / collect
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, world: int, fmt: int = 0,
-                 sync: bool = False, gather=None, keep_capture: bool = False):
+                 sync: bool = False, gather=None, keep_capture: bool = False, parity_samples: int = 0):
     import torch
     import torch.distributed as dist
     from snout_amd.rx import SnoutRx
@@ -284,7 +330,7 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
            "value": n * world * steps / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt / steps * 1e3,
            "steps": steps, "samples_per_gpu": n, "packets_per_gpu": int(len(local)),
            "decoded_pkts_per_s": len(local) * world * steps / dt,
-           "decoded_crc_ok_per_gpu": n_ok, "expected_crc_ok_per_gpu": expect,
+           "decoded_crc_ok_per_gpu": n_ok, "min_expected_crc_ok_per_gpu": expect,
            "kernel": prof.dominant_name, "kernel_ms": k_avg, "algorithmic_bytes": algo,
            "achieved_GBps": algo / (k_avg * 1e-3) / 1e9, "frac": algo / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     if n_ch > 1:
@@ -292,6 +338,8 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         res["fp32"] = {"flop_per_sample": float(PFB_FLOP[n_ch]), "achieved_TFLOPs": fl / (k_avg * 1e-3) / 1e12,
                        "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": fl / (k_avg * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
     rx.close()
+    if parity_samples:
+        res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt)
     if keep_capture:
         return res, x
     del x
@@ -363,9 +411,11 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
             return x[2 * lo:2 * (lo + (b - a))]
         caps.append((n_total, source, x))
     (nb, srcb, xb), (nz, srcz, xz) = caps
-    on_gpu = world == 1 or dist.get_backend(group) == "nccl"
+    on_gpu = (not dist.is_initialized()) or dist.get_backend(group) == "nccl"
     gdev = device if on_gpu else None
-    gb = sdist.AsyncRecordGather(gdev, group, width=80, dedup_tol=0)
+    # 96-byte BTLE wire records: 24 + (2 + 63 + 3), the longest PDU the decoder can emit (a false access-address match on
+    # a data channel carries a 6-bit length)
+    gb = sdist.AsyncRecordGather(gdev, group, width=96, dedup_tol=0)
     gz = sdist.AsyncRecordGather(gdev, group, width=160, dedup_tol=8 * 64 + 8)
     results = []
 
@@ -410,6 +460,16 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
         dt = float(tmax.item())
+    # what the record exchange ran on, and how many ranks one all_gather of rank ids actually reached
+    if dist.is_initialized():
+        ids = torch.full((1,), rank, dtype=torch.int64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        seen = torch.empty(dist.get_world_size(group), dtype=torch.int64, device=ids.device)
+        dist.all_gather_into_tensor(seen, ids, group=group)
+        assert sorted(seen.tolist()) == list(range(dist.get_world_size(group)))
+        collective = ("RCCL" if dist.get_backend(group) == "nccl" else dist.get_backend(group)) + " all_gather_into_tensor"
+        n_seen = int(seen.numel())
+    else:
+        collective, n_seen = "none (no process group: device copy)", 1
     res = None
     if rank == 0:
         rb, rz = results[-1]
@@ -427,13 +487,14 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
                "samples_per_gpu": nb_rank + nz_rank, "btle_samples_per_gpu": nb_rank, "zigbee_samples_per_gpu": nz_rank,
                "segments_per_gpu": len(sb._segs) + len(sz._segs), "segment_samples": SEG,
                "segments_per_submission": {"btle": sb.batch, "zigbee": sz.batch},
-               "value_per_gpu": total / dt / 1e6 / world,
+               "value_per_gpu": total / dt / 1e6 / world, "collective": collective, "ranks_in_collective": n_seen,
+               "device_of_rank0": int(device.index),
                "records_on_rank0": int(len(rb) + len(rz)), "decoded_crc_ok": ok_b + ok_z,
-               "expected_crc_ok": exp_b + exp_z, "decoded_pkts_per_s": (len(rb) + len(rz)) * steps / dt,
-               "sharding": "segment i -> rank i mod N; per step one all_gather of 80-B BTLE and one of 160-B "
+               "min_expected_crc_ok": exp_b + exp_z, "decoded_pkts_per_s": (len(rb) + len(rz)) * steps / dt,
+               "sharding": "segment i -> rank i mod N; per step one all_gather of 96-B BTLE and one of 160-B "
                            "802.15.4 records to rank 0 (%s), sort + de-duplication on rank 0's GPU, inside the "
-                           "timed region" % ("RCCL" if world > 1 and dist.get_backend(group) == "nccl" else
-                                             ("gloo" if world > 1 else "single rank: device copy")),
+                           "timed region" % (("RCCL" if dist.get_backend(group) == "nccl" else dist.get_backend(group))
+                                             if dist.is_initialized() else "single rank: device copy"),
                "algorithmic_bytes": 8.0 * (nb_rank + nz_rank) + 160.0 * (len(rb) + len(rz)) / world}
         res["achieved_GBps"] = res["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9
         res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
@@ -480,12 +541,22 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    assert torch.cuda.current_device() == local_rank            # LOCAL_RANK -> device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("SNOUT_BENCH_NCCL1") == "1":
+        # a one-GPU box: the record exchange of cfg #5 still runs as a real RCCL collective (world size 1), so the
+        # path an 8-GPU run takes (all_gather_into_tensor on device buffers, device dedup, pack_last_records) executes
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
 
     from snout_amd import dist as sdist
     fmt = {"cf32": 0, "sc8": 1, "sc16": 2}[args.format]
@@ -520,6 +591,8 @@ def main():
                     "frac_of_measured_read": res["achieved_GBps"] / rbest if rbest else None}
             if "fp32" in res:
                 roof["fp32"] = res["fp32"]
+                roof["fp32_frac"] = res["fp32"]["frac"]
+                roof["fp32_achieved_TFLOPs"] = res["fp32"]["achieved_TFLOPs"]
             out = {"metric": METRIC, "value": res["value"], "unit": "Msamples/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -530,34 +603,37 @@ def main():
                               "sharding": ("every rank its own segment, per-step RCCL gather of %d-B records"
                                            % WORKLOADS[headline][4]) if world > 1 else "single segment",
                               "decoded_crc_ok_per_gpu": res["decoded_crc_ok_per_gpu"],
-                              "expected_crc_ok_per_gpu": res["expected_crc_ok_per_gpu"],
+                              "min_expected_crc_ok_per_gpu": res["min_expected_crc_ok_per_gpu"],
                               "stepping": "one segment at a time" if args.sync else
                                           "pipelined: record D2H of step i overlaps step i+1"},
                    "roofline": roof}
             if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
                 ns = int(min(args.cpu_samples or CPU_SAMPLES[headline], n))
-                out["cpu_baseline"] = cpu_baseline(x, headline, ns)
+                out["cpu_baseline"], cpu_recs = cpu_baseline(x, headline, ns)
+                # the records the one-thread CPU leg just produced against the HIP path on the same samples
+                out["parity_in_run"] = parity_in_run(x, headline, ns, device, fmt, want=cpu_recs)
         del x
         torch.cuda.empty_cache()
         if world == 1 and args.workload is None and not args.no_others:
             others = {}
             k = max(3, min(args.steps, 10))
             for name in ("cfg2", "cfg4", "zigbee1"):
-                r, _ = run_workload(name, int(WORKLOADS[name][3]), k, 1, device, 0, 1)
-                others[name] = {f: r[f] for f in ("workload", "value", "unit", "ms_per_step", "steps", "kernel",
+                r, _ = run_workload(name, int(WORKLOADS[name][3]), k, 1, device, 0, 1,
+                                    parity_samples=0 if args.no_cpu else int(CPU_SAMPLES[name]) // 4)
+                others[name] = {f: r[f] for f in r if f in ("workload", "value", "unit", "ms_per_step", "steps", "kernel",
                                                   "kernel_ms", "frac", "achieved_GBps", "packets_per_gpu",
-                                                  "decoded_crc_ok_per_gpu", "expected_crc_ok_per_gpu")}
+                                                  "decoded_crc_ok_per_gpu", "min_expected_crc_ok_per_gpu", "parity_in_run")}
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
             r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, 0, 1, seconds=args.seconds)
             others["cfg5"] = {f: r5[f] for f in ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu",
-                                                 "records_on_rank0", "decoded_crc_ok", "expected_crc_ok", "frac",
+                                                 "records_on_rank0", "decoded_crc_ok", "min_expected_crc_ok", "frac", "value_per_gpu", "collective", "ranks_in_collective",
                                                  "achieved_GBps", "sharding")}
             others["cfg5"]["note"] = "what `--gpus N` measures; this is its N = 1 point"
             out["other_workloads"] = others
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -144,7 +144,18 @@ struct PfbSegs {
     uint64_t d_seg, S_seg;      // floats / doubles between their discriminator rows / sub-block sums
 };
 
-// Arguments of the matrix-pipe channelizer kernel (pfb_mfma.hip), by value.
+// Where the fused M = 16 (802.15.4) epilogue writes: discriminator rows and IIR sub-block sums of the Zigbee
+// context, plus the tables its arithmetic needs.
+struct PfbZbOut {
+    float* d;
+    uint64_t d_stride;
+    double* S;
+    uint64_t nsb;
+    const float* atan_tab;
+    const double* iir_w;
+};
+
+// Arguments of the specialised-wave channelizer kernels (pfb_spec.hip, pfb_mfma.hip), by value.
 struct PfbMfArgs {
     PfbSegs segs;
     uint64_t n, n_out;
@@ -154,12 +165,13 @@ struct PfbMfArgs {
     uint64_t y_stride;
     uint16_t* planes16;
     uint64_t plane_stride;
+    PfbZbOut zb;
 };
 // M = 40; btle: hard bits into the planes, else channel IQ into y
 int pfb_mfma_launch(uint32_t M, bool btle, int fmt, int impl, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // impl: 0 MFMA FIR, 1 VALU FIR
 
-// pfb_spec.hip: 12 specialised waves per CU (FIR + staging | FFT in registers), M = 40
-int pfb_spec_launch(uint32_t M, bool btle, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // waves: 12 or 16 per workgroup
+// pfb_spec.hip: one workgroup of specialised waves per CU (FIR + staging | FFT in registers), M = 40 and 16
+int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // mode: 0 channel IQ, 1 BTLE planes, 2 802.15.4 rows; waves: 12 or 16 per workgroup (M = 40)
 
 struct PfbCtx {
     uint32_t M = 0;

@@ -138,17 +138,6 @@ __device__ __forceinline__ void lds_barrier()
 #define SNOUT_PFB_WPE_ZB 3
 #endif
 
-// Where the fused M = 16 (802.15.4) epilogue writes: discriminator rows and IIR sub-block sums of
-// the Zigbee context, plus the tables its arithmetic needs.
-struct PfbZbOut {
-    float* d;
-    uint64_t d_stride;
-    double* S;
-    uint64_t nsb;
-    const float* atan_tab;
-    const double* iir_w;
-};
-
 template <int M> struct PfbGeom;
 #ifndef SNOUT_PFB_T64
 // 128 output times per tile: half the barriers per output of a 64-time tile, and one FIR window of 31
@@ -835,8 +824,8 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
         const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
         segs.wgs_per_seg = nwg;
         PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), planes16 ? nullptr : d_y.as<float2>(), y_stride,
-                    planes16, plane_stride};
-        if (impl >= 3) return pfb_spec_launch(40, planes16 != nullptr, fmt, impl == 3 ? 12 : 16, nwg * count, st, a);
+                    planes16, plane_stride, PfbZbOut{}};
+        if (impl >= 3) return pfb_spec_launch(40, planes16 != nullptr ? 1 : 0, fmt, impl == 3 ? 12 : 16, nwg * count, st, a);
         return pfb_mfma_launch(40, planes16 != nullptr, fmt, impl == 1 ? 0 : 1, nwg * count, st, a);
     } else if (M == 40) {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
@@ -847,6 +836,21 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
             SNOUT_PFB(40, true, (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
             SNOUT_PFB(40, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
+    } else if (impl != 0) {
+        // pfb_spec.hip, M = 16: FIR waves beside FFT + discriminator waves, one 16-wave workgroup per CU
+        const uint32_t n_tiles = cdiv(n_out, 128u);
+        const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
+        const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
+        segs.wgs_per_seg = nwg;
+        if (zbt) {
+            // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
+            const uint64_t done = (uint64_t)n_tiles * 128u;
+            if (done < zbt->d_stride)
+                for (uint32_t k = 0; k < count; k++)
+                    SNOUT_HIP(hipMemset2DAsync(zbt->d + (uint64_t)k * d_seg + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
+        }
+        PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), zbt ? nullptr : d_y.as<float2>(), y_stride, nullptr, 0, zb};
+        return pfb_spec_launch(16, zbt ? 2 : 0, fmt, 16, nwg * count, st, a);
     } else {
         const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
         // 256-thread workgroups: four per CU fit (<= 128 VGPRs, 29 KB LDS).  The fused 802.15.4 variant keeps

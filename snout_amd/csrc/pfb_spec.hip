@@ -27,6 +27,7 @@
 //   One s_barrier per tile.
 #include "common.h"
 #include "iq_fmt.h"
+#include "zb_discrim.h"
 #include <type_traits>
 #include "pfb_tables.inc"
 
@@ -119,32 +120,48 @@ __device__ __forceinline__ void lds_barrier()
 // Waves w, w + 4, w + 8, w + 12 share a SIMD: with 16 waves the SIMDs hold 3 FIR + 1 FFT, 3 + 1, 2 + 2, 2 + 2 waves =
 // 2216, 2216, 2384, 2384 issue cycles per tile (FIR wave 512, FFT wave 680), and a plain VALU stream reaches 81 % of its
 // peak at four waves per SIMD against 73 % at three (tools/fmabench.hip).
-constexpr int kFftWaves = 6;
-template <int W> struct Layout;
-template <> struct Layout<12> { static constexpr int FIR = 5, OUT = 16; };
-template <> struct Layout<16> { static constexpr int FIR = 10, OUT = 8; };
-
+// Wave layouts (W = waves per workgroup; waves w, w + 4, w + 8, w + 12 share a SIMD):
+//   M = 40, W = 12: waves 0-4 FIR (16 outputs per thread), 8 idle, 5-7 and 9-11 FFT   -- 3 waves per SIMD, <= 168 registers
+//   M = 40, W = 16: waves 0-9 FIR ( 8 outputs per thread), 10-15 FFT                  -- 4 waves per SIMD, <= 128 registers:
+//       the SIMDs hold 3 FIR + 1 FFT, 3 + 1, 2 + 2, 2 + 2 waves = 2216, 2216, 2384, 2384 issue cycles per tile (FIR wave 512,
+//       FFT wave 680), and a plain VALU stream reaches 81 % of its peak at four waves per SIMD against 73 % at three
+//       (tools/fmabench.hip): 2.6 against 2.8 ms per 8e8 samples.
+//   M = 16, W = 16: waves 0-3 FIR (8 outputs per thread), 4-15 FFT + 802.15.4 discriminator (a block is spread over six tile
+//       times): one FIR and three FFT waves on every SIMD.
+template <int M, int W> struct Layout;
+template <> struct Layout<40, 12> { static constexpr int FIR = 5, OUT = 16, FFT = 6, PERIOD = 3; };
+template <> struct Layout<40, 16> { static constexpr int FIR = 10, OUT = 8, FFT = 6, PERIOD = 3; };
+template <> struct Layout<16, 16> { static constexpr int FIR = 4, OUT = 8, FFT = 12, PERIOD = 6; };
 }  // namespace sp
 
-// Output modes
-constexpr int kSpIq = 0, kSpBtle = 1;
+// Output modes: channel IQ | BTLE hard bits into the planes (M = 40) | 802.15.4 discriminator rows + IIR sums (M = 16)
+constexpr int kSpIq = 0, kSpBtle = 1, kSpZb = 2;
 
-template <int MODE, int FMT, int W>
+template <int M, int MODE, int FMT, int W>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W / 4, W / 4)))
-void pfb_spec40(const PfbMfArgs A)
+void pfb_spec(const PfbMfArgs A)
 {
     using namespace sp;
-    constexpr int kFirWaves = Layout<W>::FIR, OUT = Layout<W>::OUT, NG = 64 / OUT;    // NG groups of OUT outputs per (branch, parity) and tile
-    constexpr int M = 40, T = 128, M1 = 8, M2 = 5, ROW = 42, D = M / 2, P = 16;
+    using L_ = Layout<M, W>;
+    constexpr int kFirWaves = L_::FIR, OUT = L_::OUT, NG = 64 / OUT;    // NG groups of OUT outputs per (branch, parity) and tile
+    constexpr int kFftWaves = L_::FFT, PERIOD = L_::PERIOD;
+    constexpr int T = 128, M1 = M == 40 ? 8 : 4, M2 = M == 40 ? 5 : 4, ROW = M == 40 ? 42 : 18, D = M / 2, P = 16;
+    constexpr bool PHASE_MAJOR = M == 40;               // rows in the FFT waves' lane order (M = 40) or in time order
     constexpr int SPAN = (T - 1) * D + M * P, NEW = T * D, OV = SPAN - NEW;
     constexpr int NST = 64 * kFirWaves;                 // threads that compute the FIR and stage
     static_assert(NST == 2 * M * NG && (NEW / 2) % NST == 0 && OV / 2 <= NST, "FIR / staging thread map");
-    constexpr bool BT = MODE == kSpBtle;
+    static_assert(2 * kFftWaves == 4 * PERIOD && (MODE != kSpBtle || M == 40) && (MODE != kSpZb || M == 16), "layout");
+    constexpr bool BT = MODE == kSpBtle, ZB = MODE == kSpZb;
 
     __shared__ float2 xs[2][SPAN];
     __shared__ float2 us[2][T * ROW];
     __shared__ float2 cfirst[BT ? kFftWaves : 1][2][BT ? M * 4 : 1];    // [wave][block parity][channel][phase]: y of the block's first four times
     __shared__ float2 clast[BT ? kFftWaves : 1][BT ? M * 4 : 1];        // ... of its last four
+    // 802.15.4: fast_atan2f table, IIR weights, y of each block's last output time, each wave's d values (for the S_j sums)
+    __shared__ float atan_s[ZB ? 257 : 1];
+    __shared__ double wts_s[ZB ? 64 : 1];
+    __shared__ float2 ylast[ZB ? kFftWaves : 1][ZB ? M : 1];
+    __shared__ float dls[ZB ? kFftWaves : 1][ZB ? M * 65 : 1];
 
     const uint32_t seg = blockIdx.x / A.segs.wgs_per_seg, bid = blockIdx.x - seg * A.segs.wgs_per_seg;
     const void* __restrict__ x = A.segs.x[seg];
@@ -156,12 +173,18 @@ void pfb_spec40(const PfbMfArgs A)
     uint32_t t_end = t_begin + A.tiles_per_wg;
     if (t_end > n_tiles) t_end = n_tiles;
     if (t_begin >= t_end) return;
-    // BTLE: the first four output times of the tile behind the range complete the range's last symbols
-    const uint32_t t_stop = (BT && t_end < n_tiles) ? t_end + 1u : t_end;
-    const int NTL = (int)(t_stop - t_begin);            // tiles this workgroup computes
-    const int IT = NTL + 4;                              // barriers after the first one (pipeline drain included)
+    // tiles this workgroup computes: its range, plus (BTLE) the tile behind it, whose first four output times complete the
+    // range's last symbols, or (802.15.4) the tile before it, whose last output time the first discriminator value needs
+    const uint32_t t_lo = (ZB && t_begin > 0u) ? t_begin - 1u : t_begin;
+    const uint32_t t_hi = (BT && t_end < n_tiles) ? t_end + 1u : t_end;
+    const int NTL = (int)(t_hi - t_lo);
+    const int IT = NTL + PERIOD + 1;                     // barriers after the first one (pipeline drain included)
 
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    if constexpr (ZB) {
+        for (int i = t; i < 257; i += 64 * W) atan_s[i] = A.zb.atan_tab[i];
+        if (t < 64) wts_s[t] = A.zb.iir_w[t];
+    }
 #ifdef SNOUT_MF_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -181,7 +204,9 @@ void pfb_spec40(const PfbMfArgs A)
         const uint32_t rd = (uint32_t)((r + e * D + OUT * grp * M) * 8);                      // window start, bytes
         // row of output m = e + 2 (OUT grp + i), rows in the FFT waves' lane order (64 (m / 64) + 16 (m mod 4) + (m mod 64) / 4):
         //   OUT = 16: 64 (grp / 2) + 16 (e + 2 (i & 1)) + 8 (grp & 1) + i / 2;   OUT = 8: 64 (grp / 4) + 16 (e + 2 (i & 1)) + 4 (grp & 3) + i / 2
-        const uint32_t wr = OUT == 16 ? (uint32_t)(((64 * (grp >> 1) + 16 * e + 8 * (grp & 1)) * ROW + r) * 8)
+        //   time order (M = 16): row m
+        const uint32_t wr = !PHASE_MAJOR ? (uint32_t)(((e + 2 * OUT * grp) * ROW + r) * 8)
+                          : OUT == 16 ? (uint32_t)(((64 * (grp >> 1) + 16 * e + 8 * (grp & 1)) * ROW + r) * 8)
                                       : (uint32_t)(((64 * (grp >> 2) + 16 * e + 4 * (grp & 3)) * ROW + r) * 8);
 
         auto load_pair = [&](uint64_t g) -> Raw {                  // samples g, g+1 (g even), zero past n
@@ -249,16 +274,16 @@ void pfb_spec40(const PfbMfArgs A)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int i = i0 + j;
-                    *reinterpret_cast<float2*>(uo + (32 * (i & 1) + (i >> 1)) * ROW * 8) = make_float2(acc[j].x, acc[j].y);
+                    *reinterpret_cast<float2*>(uo + (PHASE_MAJOR ? 32 * (i & 1) + (i >> 1) : 2 * i) * ROW * 8) = make_float2(acc[j].x, acc[j].y);
                 }
             }
         };
         // ---- prologue: the whole span of the first tile; the second tile's new samples requested
         {
             float4* xb = reinterpret_cast<float4*>(&xs[0][0]);
-            const uint64_t in0 = (uint64_t)t_begin * NEW;
+            const uint64_t in0 = (uint64_t)t_lo * NEW;
             for (uint32_t q = (uint32_t)tf; q < (uint32_t)(SPAN / 2); q += NST) xb[q] = iq_pair_cvt<FMT>(load_pair(in0 + 2ull * q));
-            if (1 < NTL) fetch(pre[1], t_begin + 1u);
+            if (1 < NTL) fetch(pre[1], t_lo + 1u);
         }
         lds_barrier();
         for (int it = 0; it < IT; it += 2) {
@@ -269,7 +294,7 @@ void pfb_spec40(const PfbMfArgs A)
                     if (i2 < NTL) {
                         // tile i2 + 2's samples: two tiles ahead into the set tile i2's came from; tile i2 + 1's (requested
                         // one tile ago) go to LDS behind this tile's FIR: a load has one tile time + the FIR to arrive
-                        if (i2 + 2 < NTL) fetch(pre[hb], t_begin + (uint32_t)i2 + 2u);
+                        if (i2 + 2 < NTL) fetch(pre[hb], t_lo + (uint32_t)i2 + 2u);
                         SP_STAMP(0);
                         if (hb == 0) fir_tile(std::integral_constant<int, 0>{});
                         else         fir_tile(std::integral_constant<int, 1>{});
@@ -282,7 +307,7 @@ void pfb_spec40(const PfbMfArgs A)
                 }
             }
         }
-    } else if (W == 12 && w == 8) {
+    } else if (M == 40 && W == 12 && w == 8) {
         // wave 8 shares its SIMD with FIR waves 0 and 4: it stays idle and only keeps the barriers' count
         for (int i = 0; i < IT + 1; i++) lds_barrier();
     } else {
@@ -291,16 +316,17 @@ void pfb_spec40(const PfbMfArgs A)
         // =====================================================================================
         // Wave f takes the blocks b = f + 6 k (block b = 64-time half b & 1 of tile b >> 1): tile j = f / 2 + 3 k, half
         // f & 1; a block takes three tile times: Q1 (row, first stage) | barrier | Q2 | barrier | Q3 | barrier.
-        const int f = W == 12 ? (w < 8 ? w - kFirWaves : w - kFirWaves - 1) : w - kFirWaves, j0 = f >> 1, half = f & 1;
+        const int f = (M == 40 && W == 12) ? (w < 8 ? w - kFirWaves : w - kFirWaves - 1) : w - kFirWaves, j0 = f >> 1, half = f & 1;
         // The FFT is dependency chains; the FIR waves' 256 independent packed FMAs per tile are always ready and, being the
         // older waves, would win every arbitration: FFT waves issue first (priority, then age), the FIR fills their gaps.
 #ifndef SNOUT_SP_PRIO_FFT
 #define SNOUT_SP_PRIO_FFT 2
 #endif
         __builtin_amdgcn_s_setprio(SNOUT_SP_PRIO_FFT);
-        const float* const tw = kTw40;
+        const float* const tw = M == 40 ? kTw40 : kTw16;
         const float c5_1 = kTw5[2], c5_2 = kTw5[4], s5_1 = -kTw5[3], s5_2 = -kTw5[5];
-        const uint32_t mloc = 4u * (uint32_t)(l & 15) + (uint32_t)(l >> 4);      // output time of this lane within its block
+        // output time of this lane within its block
+        const uint32_t mloc = PHASE_MAJOR ? 4u * (uint32_t)(l & 15) + (uint32_t)(l >> 4) : (uint32_t)l;
         int itc = 0;
 #ifdef SNOUT_MF_STAMPS
         auto bar = [&]() { SP_STAMP(3); lds_barrier(); itc++; SP_STAMP(2); };
@@ -310,132 +336,239 @@ void pfb_spec40(const PfbMfArgs A)
         bar();                                                       // the FIR waves' prologue
         for (int i = 0; i <= j0; i++) bar();                         // barrier j + 2 ends tile j's FIR
 
-        // BTLE: state of the block whose last symbols wait for the next block's first output times.
-        // Lane k < 40 holds the 64 hard bits of channel k.
-        uint32_t pm_lo = 0, pm_hi = 0;
-        uint64_t pend_m0 = 0;
-        int pend_par = 0;
-        bool pending = false;
-        auto finalize = [&]() {
-            if constexpr (BT) {
-                if (pending && l < M) {
-                    const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;           // bits exist for m < n_out - 4
-                    // the block behind this one is the next wave's (wave 0's NEXT block behind wave 5's)
-                    const int fs = f == kFftWaves - 1 ? 0 : f + 1;
-                    const int spar = f == kFftWaves - 1 ? pend_par ^ 1 : pend_par;
-                    const float4* la = reinterpret_cast<const float4*>(&clast[f][l * 4]);
-                    const float4* fi = reinterpret_cast<const float4*>(&cfirst[fs][spar][l * 4]);
-                    const float4 l01 = la[0], l23 = la[1], f01 = fi[0], f23 = fi[1];
-                    const uint32_t b0 = (l01.x * f01.y) > (f01.x * l01.y) ? 1u : 0u;
-                    const uint32_t b1 = (l01.z * f01.w) > (f01.z * l01.w) ? 1u : 0u;
-                    const uint32_t b2 = (l23.x * f23.y) > (f23.x * l23.y) ? 1u : 0u;
-                    const uint32_t b3 = (l23.z * f23.w) > (f23.z * l23.w) ? 1u : 0u;
-                    const uint32_t lo = (pm_lo & 0x7FFF7FFFu) | (b0 << 15) | (b1 << 31);
-                    const uint32_t hi = (pm_hi & 0x7FFF7FFFu) | (b2 << 15) | (b3 << 31);
-                    // symbols whose sample exists: m0 + 4 sy + j < nbits, a prefix of the 16 per phase
-                    const uint32_t left = nbits > pend_m0 ? (uint32_t)(nbits - pend_m0 < 64u ? nbits - pend_m0 : 64u) : 0u;
-                    uint16_t* dst = planes16 + ((uint64_t)l * A.plane_stride + (pend_m0 >> 8) * 4u) * 4u + (uint32_t)((pend_m0 & 255u) >> 6);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t cnt = left > (uint32_t)j ? (left - (uint32_t)j + 3u) >> 2 : 0u;     // <= 16
-                        const uint32_t v = ((j < 2 ? lo : hi) >> (16 * (j & 1))) & 0xFFFFu;
-                        dst[4 * j] = (uint16_t)(v & ((1u << cnt) - 1u));
+        if constexpr (M == 40) {
+            // BTLE: state of the block whose last symbols wait for the next block's first output times.
+            // Lane k < 40 holds the 64 hard bits of channel k.
+            uint32_t pm_lo = 0, pm_hi = 0;
+            uint64_t pend_m0 = 0;
+            int pend_par = 0;
+            bool pending = false;
+            auto finalize = [&]() {
+                if constexpr (BT) {
+                    if (pending && l < M) {
+                        const uint64_t nbits = n_out >= 4 ? n_out - 4 : 0;           // bits exist for m < n_out - 4
+                        // the block behind this one is the next wave's (wave 0's NEXT block behind wave 5's)
+                        const int fs = f == kFftWaves - 1 ? 0 : f + 1;
+                        const int spar = f == kFftWaves - 1 ? pend_par ^ 1 : pend_par;
+                        const float4* la = reinterpret_cast<const float4*>(&clast[f][l * 4]);
+                        const float4* fi = reinterpret_cast<const float4*>(&cfirst[fs][spar][l * 4]);
+                        const float4 l01 = la[0], l23 = la[1], f01 = fi[0], f23 = fi[1];
+                        const uint32_t b0 = (l01.x * f01.y) > (f01.x * l01.y) ? 1u : 0u;
+                        const uint32_t b1 = (l01.z * f01.w) > (f01.z * l01.w) ? 1u : 0u;
+                        const uint32_t b2 = (l23.x * f23.y) > (f23.x * l23.y) ? 1u : 0u;
+                        const uint32_t b3 = (l23.z * f23.w) > (f23.z * l23.w) ? 1u : 0u;
+                        const uint32_t lo = (pm_lo & 0x7FFF7FFFu) | (b0 << 15) | (b1 << 31);
+                        const uint32_t hi = (pm_hi & 0x7FFF7FFFu) | (b2 << 15) | (b3 << 31);
+                        // symbols whose sample exists: m0 + 4 sy + j < nbits, a prefix of the 16 per phase
+                        const uint32_t left = nbits > pend_m0 ? (uint32_t)(nbits - pend_m0 < 64u ? nbits - pend_m0 : 64u) : 0u;
+                        uint16_t* dst = planes16 + ((uint64_t)l * A.plane_stride + (pend_m0 >> 8) * 4u) * 4u + (uint32_t)((pend_m0 & 255u) >> 6);
+    #pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t cnt = left > (uint32_t)j ? (left - (uint32_t)j + 3u) >> 2 : 0u;     // <= 16
+                            const uint32_t v = ((j < 2 ? lo : hi) >> (16 * (j & 1))) & 0xFFFFu;
+                            dst[4 * j] = (uint16_t)(v & ((1u << cnt) - 1u));
+                        }
+                    }
+                    pending = false;
+                }
+            };
+
+            int kblk = 0;
+            for (int j = j0; j < NTL; j += 3, kblk++) {
+                const uint32_t tile = t_lo + (uint32_t)j;
+                const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)half;
+                const bool emit = tile < t_end;                          // the tile behind the range only supplies its first four times
+                const bool need = emit || half == 0;
+                const int par = kblk & 1;
+                // ---- Q1: the row, 8-point DFTs over n1 and the twiddles W_40^{n2 k1}
+                cf Bv[M2][M1];
+                if (need) {
+                    const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
+                    cf u[M];
+    #pragma unroll
+                    for (int q = 0; q < M / 2; q++) {
+                        const float4 v = rowp[q];
+                        u[2 * q] = cf{v.x, v.y};
+                        u[2 * q + 1] = cf{v.z, v.w};
+                    }
+    #pragma unroll
+                    for (int n2 = 0; n2 < M2; n2++) {
+                        cf a[M1], X[M1];
+    #pragma unroll
+                        for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
+                        dft8(a, X);
+    #pragma unroll
+                        for (int k1 = 0; k1 < M1; k1++) {
+                            const int jj = (n2 * k1) % M;
+                            Bv[n2][k1] = jj == 0 ? X[k1] : cmul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
+                        }
                     }
                 }
-                pending = false;
-            }
-        };
-
-        int kblk = 0;
-        for (int j = j0; j < NTL; j += 3, kblk++) {
-            const uint32_t tile = t_begin + (uint32_t)j;
-            const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)half;
-            const bool emit = tile < t_end;                          // the tile behind the range only supplies its first four times
-            const bool need = emit || half == 0;
-            const int par = kblk & 1;
-            // ---- Q1: the row, 8-point DFTs over n1 and the twiddles W_40^{n2 k1}
-            cf Bv[M2][M1];
-            if (need) {
-                const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
-                cf u[M];
-#pragma unroll
-                for (int q = 0; q < M / 2; q++) {
-                    const float4 v = rowp[q];
-                    u[2 * q] = cf{v.x, v.y};
-                    u[2 * q + 1] = cf{v.z, v.w};
+                bar();
+                // ---- Q2, Q3: 5-point DFTs over n2 per k1, epilogue per channel k = k1 + 8 k2
+                finalize();                       // the block before this one: its successor's first output times are there now
+                uint32_t m_lo = 0, m_hi = 0;
+                auto do_k1 = [&](int k1) {
+                    cf b[M2], Y[M2];
+    #pragma unroll
+                    for (int n2 = 0; n2 < M2; n2++) b[n2] = Bv[n2][k1];
+                    dft5(b, Y, c5_1, c5_2, s5_1, s5_2);
+                    if constexpr (BT) {
+                        // bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m]); m + 4 is the next lane of the 16-lane row.  The
+                        // factor (-1)^{km} is the same for m and m + 4 and cancels in both products.
+    #pragma unroll
+                        for (int k2 = 0; k2 < M2; k2++) {
+                            const int k = k1 + M1 * k2;
+                            const float qn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].im), 0x101, 0xF, 0xF, true));
+                            const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].re), 0x101, 0xF, 0xF, true));
+                            const uint64_t mk = __builtin_amdgcn_ballot_w64((Y[k2].re * qn) > (in * Y[k2].im));
+                            m_lo = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)mk, k, (int)m_lo);
+                            m_hi = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)(mk >> 32), k, (int)m_hi);
+                        }
+                        const int li = l & 15;
+                        if (li == 0) {                                   // first four output times of the block
+    #pragma unroll
+                            for (int k2 = 0; k2 < M2; k2++) cfirst[f][par][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
+                        } else if (li == 15) {                           // last four
+    #pragma unroll
+                            for (int k2 = 0; k2 < M2; k2++) clast[f][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
+                        }
+                    } else {
+                        const uint64_t mg = m0b + mloc;
+                        if (mg < n_out) {
+    #pragma unroll
+                            for (int k2 = 0; k2 < M2; k2++) {
+                                const int k = k1 + M1 * k2;
+                                cf v = Y[k2];
+                                if ((k & 1) && (mg & 1)) { v.re = -v.re; v.im = -v.im; }
+                                A.y[(uint64_t)k * A.y_stride + mg] = make_float2(v.re, v.im);
+                            }
+                        }
+                    }
+                };
+                if (need) {
+    #pragma unroll
+                    for (int k1 = 0; k1 < M1 / 2; k1++) do_k1(k1);
                 }
+                bar();
+                if (need) {
+    #pragma unroll
+                    for (int k1 = M1 / 2; k1 < M1; k1++) do_k1(k1);
+                    if constexpr (BT) {
+                        pm_lo = m_lo; pm_hi = m_hi; pend_m0 = m0b; pend_par = par; pending = emit;
+                    }
+                }
+                bar();
+            }
+            // ---- drain: the block behind the last one is finished one barrier later; then keep step with the FIR waves
+            if (itc < IT + 1) bar();
+            finalize();
+        } else {
+            // =================================================================================
+            // M = 16: 4 x 4 FFT in registers, then (802.15.4) the FM discriminator of the thread's 16 channels
+            // =================================================================================
+            // Wave f takes the blocks b = f + 12 k: tile j = f / 2 + 6 k, half f & 1; six tile times per block:
+            //   Q1 row + FFT (+ y of the block's last output time into LDS for the block behind it) | Q2..Q5 four channels'
+            //   discriminator values each: d[m] = fast_atan2f(y[m] conj y[m-1]) (zb_discrim.h), y[m-1] from the lane below
+            //   (whole-wave DPP shift; lane 0: the block before) | Q6 the IIR sub-block sums S_j of the block's 64 values
+            //   per channel, in the oracle's order (four partial sums of 16 sequential terms, S = (P0 + P1) + (P2 + P3)).
+            float* const dl = &dls[ZB ? f : 0][0];
+            int kblk = 0;
+            for (int j = j0; j < NTL; j += PERIOD, kblk++) {
+                const uint32_t tile = t_lo + (uint32_t)j;
+                const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)half;
+                const bool emit = tile >= t_begin;                   // the tile before the range only supplies y[m0 - 1]
+                const uint64_t mg = m0b + mloc;
+                // ---- Q1: the row and the FFT; y_k[m] = (-1)^{km} X[k]
+                cf y[M];
+                {
+                    const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
+                    cf u[M];
 #pragma unroll
-                for (int n2 = 0; n2 < M2; n2++) {
-                    cf a[M1], X[M1];
+                    for (int q = 0; q < M / 2; q++) {
+                        const float4 v = rowp[q];
+                        u[2 * q] = cf{v.x, v.y};
+                        u[2 * q + 1] = cf{v.z, v.w};
+                    }
+                    cf Bv[M2][M1];
 #pragma unroll
-                    for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
-                    dft8(a, X);
+                    for (int n2 = 0; n2 < M2; n2++) {
+                        cf a[M1], X[M1];
+#pragma unroll
+                        for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
+                        dft4(a, X);
+#pragma unroll
+                        for (int k1 = 0; k1 < M1; k1++) {
+                            const int jj = (n2 * k1) % M;
+                            Bv[n2][k1] = jj == 0 ? X[k1] : cmul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
+                        }
+                    }
 #pragma unroll
                     for (int k1 = 0; k1 < M1; k1++) {
-                        const int jj = (n2 * k1) % M;
-                        Bv[n2][k1] = jj == 0 ? X[k1] : cmul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
-                    }
-                }
-            }
-            bar();
-            // ---- Q2, Q3: 5-point DFTs over n2 per k1, epilogue per channel k = k1 + 8 k2
-            finalize();                       // the block before this one: its successor's first output times are there now
-            uint32_t m_lo = 0, m_hi = 0;
-            auto do_k1 = [&](int k1) {
-                cf b[M2], Y[M2];
+                        cf b[M2], Y[M2];
 #pragma unroll
-                for (int n2 = 0; n2 < M2; n2++) b[n2] = Bv[n2][k1];
-                dft5(b, Y, c5_1, c5_2, s5_1, s5_2);
-                if constexpr (BT) {
-                    // bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m]); m + 4 is the next lane of the 16-lane row.  The
-                    // factor (-1)^{km} is the same for m and m + 4 and cancels in both products.
-#pragma unroll
-                    for (int k2 = 0; k2 < M2; k2++) {
-                        const int k = k1 + M1 * k2;
-                        const float qn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].im), 0x101, 0xF, 0xF, true));
-                        const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].re), 0x101, 0xF, 0xF, true));
-                        const uint64_t mk = __builtin_amdgcn_ballot_w64((Y[k2].re * qn) > (in * Y[k2].im));
-                        m_lo = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)mk, k, (int)m_lo);
-                        m_hi = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)(mk >> 32), k, (int)m_hi);
-                    }
-                    const int li = l & 15;
-                    if (li == 0) {                                   // first four output times of the block
-#pragma unroll
-                        for (int k2 = 0; k2 < M2; k2++) cfirst[f][par][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
-                    } else if (li == 15) {                           // last four
-#pragma unroll
-                        for (int k2 = 0; k2 < M2; k2++) clast[f][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
-                    }
-                } else {
-                    const uint64_t mg = m0b + mloc;
-                    if (mg < n_out) {
+                        for (int n2 = 0; n2 < M2; n2++) b[n2] = Bv[n2][k1];
+                        dft4(b, Y);
 #pragma unroll
                         for (int k2 = 0; k2 < M2; k2++) {
                             const int k = k1 + M1 * k2;
                             cf v = Y[k2];
                             if ((k & 1) && (mg & 1)) { v.re = -v.re; v.im = -v.im; }
-                            A.y[(uint64_t)k * A.y_stride + mg] = make_float2(v.re, v.im);
+                            y[k] = v;
                         }
                     }
                 }
-            };
-            if (need) {
+                if constexpr (ZB) {
+                    if (l == 63) {
 #pragma unroll
-                for (int k1 = 0; k1 < M1 / 2; k1++) do_k1(k1);
-            }
-            bar();
-            if (need) {
+                        for (int k = 0; k < M; k++) ylast[f][k] = make_float2(y[k].re, y[k].im);
+                    }
+                }
+                bar();
+                if constexpr (ZB) {
+                    // y[m0 - 1]: of the block before this one (the wave before; wave 11's previous block for wave 0), zero
+                    // in front of the very first block
+                    const bool have_prev = j > 0 || half == 1;
+                    const float2* yp = &ylast[f == 0 ? kFftWaves - 1 : f - 1][0];
+                    const uint32_t left = n_out > m0b ? (uint32_t)(n_out - m0b < 64u ? n_out - m0b : 64u) : 0u;   // outputs of this block that exist
 #pragma unroll
-                for (int k1 = M1 / 2; k1 < M1; k1++) do_k1(k1);
-                if constexpr (BT) {
-                    pm_lo = m_lo; pm_hi = m_hi; pend_m0 = m0b; pend_par = par; pending = emit;
+                    for (int q = 0; q < 4; q++) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int k = 4 * q + kk;
+                            const float2 pv = have_prev ? yp[k] : make_float2(0.0f, 0.0f);
+                            float2 p;
+                            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.x), __float_as_int(y[k].re), 0x138, 0xF, 0xF, false));
+                            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.y), __float_as_int(y[k].im), 0x138, 0xF, 0xF, false));
+                            float v = zb_discriminate(make_float2(y[k].re, y[k].im), p, atan_s);
+                            if (mloc >= left) v = 0.0f;
+                            if (emit) A.zb.d[(uint64_t)seg * A.segs.d_seg + (uint64_t)k * A.zb.d_stride + mg] = v;
+                            dl[k * 65 + l] = v;
+                        }
+                        bar();
+                    }
+                    // S_j of this block's sub-block of every channel: lane <-> (channel l / 4, part l & 3)
+                    {
+                        const int part = l & 3, kk = l >> 2;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 16; i++)
+                            acc = acc + wts_s[63 - (16 * part + i)] * (double)dl[kk * 65 + 16 * part + i];
+                        acc = acc + __shfl_down(acc, 1);
+                        acc = acc + __shfl_down(acc, 2);
+                        const uint64_t jsb = m0b >> 6;
+                        if (emit && part == 0 && jsb < A.zb.nsb) A.zb.S[(uint64_t)seg * A.segs.S_seg + (uint64_t)kk * A.zb.nsb + jsb] = acc;
+                    }
+                    bar();
+                } else {
+                    if (mg < n_out) {
+#pragma unroll
+                        for (int k = 0; k < M; k++) A.y[(uint64_t)k * A.y_stride + mg] = make_float2(y[k].re, y[k].im);
+                    }
+                    for (int q = 0; q < PERIOD - 1; q++) bar();
                 }
             }
-            bar();
         }
-        // ---- drain: the block behind the last one is finished one barrier later; then keep step with the FIR waves
-        if (itc < IT + 1) bar();
-        finalize();
         while (itc < IT + 1) bar();
     }
 #ifdef SNOUT_MF_STAMPS
@@ -457,17 +590,22 @@ extern "C" int snout_debug_sp_stamps(unsigned long long* out, uint32_t n)
 }
 #endif
 
-int pfb_spec_launch(uint32_t M, bool btle, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
+int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
 {
-#define SNOUT_SP(MODE, WW)                                                                                 \
+#define SNOUT_SP(MM, MODE, WW)                                                                             \
     do {                                                                                                  \
-        if (fmt == kFmtSc8) hipLaunchKernelGGL((pfb_spec40<MODE, kFmtSc8, WW>), dim3(grid), dim3(64 * WW), 0, st, a);        \
-        else if (fmt == kFmtSc16) hipLaunchKernelGGL((pfb_spec40<MODE, kFmtSc16, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-        else hipLaunchKernelGGL((pfb_spec40<MODE, kFmtCf32, WW>), dim3(grid), dim3(64 * WW), 0, st, a);                      \
+        if (fmt == kFmtSc8) hipLaunchKernelGGL((pfb_spec<MM, MODE, kFmtSc8, WW>), dim3(grid), dim3(64 * WW), 0, st, a);        \
+        else if (fmt == kFmtSc16) hipLaunchKernelGGL((pfb_spec<MM, MODE, kFmtSc16, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
+        else hipLaunchKernelGGL((pfb_spec<MM, MODE, kFmtCf32, WW>), dim3(grid), dim3(64 * WW), 0, st, a);                      \
     } while (0)
-    if (M != 40) return SNOUT_EINVAL;
-    if (waves == 12) { if (btle) SNOUT_SP(kSpBtle, 12); else SNOUT_SP(kSpIq, 12); }
-    else             { if (btle) SNOUT_SP(kSpBtle, 16); else SNOUT_SP(kSpIq, 16); }
+    if (M == 40 && mode != kSpZb) {
+        if (waves == 12) { if (mode == kSpBtle) SNOUT_SP(40, kSpBtle, 12); else SNOUT_SP(40, kSpIq, 12); }
+        else             { if (mode == kSpBtle) SNOUT_SP(40, kSpBtle, 16); else SNOUT_SP(40, kSpIq, 16); }
+    } else if (M == 16 && mode != kSpBtle) {
+        if (mode == kSpZb) SNOUT_SP(16, kSpZb, 16); else SNOUT_SP(16, kSpIq, 16);
+    } else {
+        return SNOUT_EINVAL;
+    }
 #undef SNOUT_SP
     SNOUT_HIP(hipGetLastError());
     return 0;

@@ -680,8 +680,10 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     out->n_hits = s.h_totals[0];
     out->dominant_launches = 1;
     if (h->wide) {
-        if (h->pfb.M == 40 && h->pfb.impl != 0)          // which kernel PfbCtx::run_batch launches for M = 40
-            snprintf(out->dominant_name, sizeof(out->dominant_name), "%s", h->pfb.impl >= 3 ? "pfb_spec40" : "pfb_mfma<40>");
+        if (h->pfb.impl != 0 && (h->pfb.M == 16 || h->pfb.impl >= 3))       // which kernel PfbCtx::run_batch launches
+            snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_spec%u", h->pfb.M);
+        else if (h->pfb.impl != 0)
+            snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_mfma<40>");
         else
             snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);
     } else if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
