@@ -355,7 +355,7 @@ def read_peak(x, device):
     best, mean = C.c_float(0), C.c_float(0)
     nbytes = min(x.numel() * x.element_size(), 8 << 30)
     st = torch.cuda.current_stream(device).cuda_stream
-    _ffi.check(lib.snout_hbm_read_gbps(C.c_void_p(x.data_ptr()), nbytes, 10, C.c_void_p(st),
+    _ffi.check(lib.snout_bench_hbm_read_gbps(C.c_void_p(x.data_ptr()), nbytes, 10, C.c_void_p(st),
                                        C.byref(best), C.byref(mean)))
     return float(best.value), float(mean.value)
 

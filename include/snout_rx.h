@@ -93,8 +93,10 @@ typedef struct snout_rx_cfg {
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
 typedef struct snout_pkt {
-    uint64_t sample_index;    /* BTLE: first sample of the access address; Zigbee: sample at which
-                                 the first preamble symbol was recognised. In channel samples,
+    uint64_t sample_index;    /* BTLE: first sample of the access address; Zigbee: window start of the
+                                 chip 319 chips before the one that completes the SFD, i.e. the first
+                                 chip of a regular preamble + SFD (the same for every sink that finds the
+                                 frame; the packet sink itself reports no position). In channel samples,
                                  plus first_sample_index of the call.                            */
     uint32_t proto;           /* SNOUT_PROTO_*                                                   */
     uint16_t channel;         /* protocol channel number (BTLE 0..39, Zigbee 11..26)             */
@@ -160,8 +162,10 @@ int  snout_rx_submit_dev  (snout_rx* h, const void* iq_dev, uint64_t n_samples,
 int  snout_rx_submit_batch_dev(snout_rx* h, const void* const* iq_devs, uint32_t count, uint64_t n_samples,
                                const uint64_t* first_sample_index, const uint64_t* min_sample_index,
                                void* hip_stream);
-/* 1 if the oldest submitted segment has finished (its collect will not wait), 0 if not yet (or nothing
- * is pending), negative on error: lets one host thread drive several handles without blocking on one. */
+/* 1 if the oldest submitted segment has finished, 0 if not yet (or nothing is pending), negative on error:
+ * lets one host thread drive several handles without blocking on one.  After a 1 the collect does not wait for
+ * the device -- unless the segment exceeded a capacity (hits per chunk, frames per lane, candidates): collect
+ * then grows it and runs the segment again before it returns, as the synchronous entry points do. */
 int  snout_rx_poll        (snout_rx* h);
 int  snout_rx_collect     (snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out);
 int  snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out);
@@ -190,13 +194,6 @@ int  snout_rx_profile_history(snout_rx* h, float* ms, uint32_t cap, uint32_t* n_
  * written (<= dst_cap; SNOUT_EOVERFLOW if the segment had more). */
 int  snout_rx_pack_last_records(snout_rx* h, void* dst_dev, uint64_t dst_cap, uint32_t width, uint64_t own_from,
                                 void* hip_stream, uint64_t* n_packed);
-
-/* Measurement aid (bench.py, SURVEY.md §8d "measured-copy-peak"): read-only streaming rate, in GB/s,
- * of `bytes` bytes of device memory at `dev` (a fully coalesced 16-byte-per-lane grid-stride read
- * kernel, `reps` timed launches after one warm-up, HIP events on `hip_stream`).  Not part of the
- * receive path; no reference counterpart. */
-int  snout_hbm_read_gbps(const void* dev, uint64_t bytes, uint32_t reps, void* hip_stream,
-                         float* gbps_best, float* gbps_mean);
 
 /* Host-side formatters for the two consumer contracts. */
 /* btle_rx stdout grammar (snout/core/message.py:214-215,226-236). Returns bytes written

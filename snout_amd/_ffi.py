@@ -24,7 +24,7 @@ EXPORTS = [
     "snout_host_alloc", "snout_host_free", "snout_rx_soft", "snout_rx_profile",
     "snout_rx_profile_history", "snout_btle_format_line", "snout_rftap_encap",
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
-    "snout_strerror", "snout_last_error", "snout_abi_version", "snout_hbm_read_gbps",
+    "snout_strerror", "snout_last_error", "snout_abi_version", "snout_bench_hbm_read_gbps",
     "snout_rx_pack_last_records", "snout_rx_submit_batch_dev", "snout_rx_poll",
 ]
 
@@ -121,8 +121,8 @@ def load() -> C.CDLL:
     lib.snout_last_error.restype = C.c_char_p
     lib.snout_rx_pack_last_records.argtypes = [vp, vp, u64, C.c_uint32, u64, vp, C.POINTER(u64)]
     lib.snout_rx_pack_last_records.restype = C.c_int
-    lib.snout_hbm_read_gbps.argtypes = [vp, u64, C.c_uint32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    lib.snout_hbm_read_gbps.restype = C.c_int
+    lib.snout_bench_hbm_read_gbps.argtypes = [vp, u64, C.c_uint32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.snout_bench_hbm_read_gbps.restype = C.c_int
     lib.snout_abi_version.argtypes = []
     lib.snout_abi_version.restype = C.c_uint32
     if lib.snout_abi_version() != ABI_VERSION:

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void hbm_read(const f4* __restrict__ p, uint64
 
 using namespace snout;
 
-extern "C" int snout_hbm_read_gbps(const void* dev, uint64_t bytes, uint32_t reps, void* hip_stream,
+extern "C" int snout_bench_hbm_read_gbps(const void* dev, uint64_t bytes, uint32_t reps, void* hip_stream,
                                    float* gbps_best, float* gbps_mean)
 {
     if (!dev || bytes < (1u << 20) || !gbps_best) return SNOUT_EINVAL;

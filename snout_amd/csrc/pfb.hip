@@ -792,7 +792,10 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
                       uint64_t plane_stride, uint64_t planes_seg, const PfbZbTarget* zbt, uint64_t d_seg,
                       uint64_t S_seg, int fmt)
 {
-    if (count == 0 || count > kMaxBatch || (count > 1 && !planes16 && !zbt)) return SNOUT_EINVAL;
+    if (count == 0 || count > kMaxBatch || (count > 1 && !planes16 && !zbt)) {
+        set_last_error("channelizer batch of %u segments (1..%u; more than one only in the fused modes)", count, kMaxBatch);
+        return SNOUT_EINVAL;
+    }
     PfbSegs segs{};
     for (uint32_t k = 0; k < count; k++) segs.x[k] = iqs[k];
     segs.planes_seg = planes_seg; segs.d_seg = d_seg; segs.S_seg = S_seg;

@@ -486,7 +486,10 @@ int snout_rx_submit_batch_dev(snout_rx* h, const void* const* iq_devs, uint32_t 
         if (h->wide) {
             h->pfb.n_out = 0;
             if (n_samples) {
-                if (int rc = h->pfb.run(iq_dev, n_samples, s.stream, nullptr, 0, nullptr, (int)h->cfg.sample_format)) return rc;
+                if (int rc = h->pfb.run(iq_dev, n_samples, s.stream, nullptr, 0, nullptr, (int)h->cfg.sample_format)) {
+                    h->n_submitted--;           // nothing was submitted: keep the work-set rotation in phase with the slot ring
+                    return rc;
+                }
             }
         }
         s.h_totals[0] = s.h_totals[1] = s.h_totals[2] = 0;

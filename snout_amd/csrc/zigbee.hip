@@ -939,6 +939,7 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
     for (uint32_t i = 0; i < raw; i++) {
         uint32_t trig[kResolveSet], endc[kResolveSet];
         int ns = 0;
+        bool full = false;
         const uint32_t* me = reinterpret_cast<const uint32_t*>(&stage[(size_t)g * K + i].bytes[128]);
         trig[0] = me[0]; endc[0] = me[1]; ns = 1;
         uint32_t tmin = me[0];
@@ -957,7 +958,8 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
             }
             const uint32_t* r = reinterpret_cast<const uint32_t*>(&stage[(size_t)gl * K + (uint32_t)idx].bytes[128]);
             const uint32_t rt = r[0], re = r[1];
-            if (re >= tmin && ns < kResolveSet) {           // it reaches something gathered: it matters
+            if (re >= tmin) {                               // it reaches something gathered: it matters
+                if (ns == kResolveSet) { full = true; break; }
                 trig[ns] = rt; endc[ns] = re; ns++;
                 tmin = rt < tmin ? rt : tmin;
             }
@@ -966,10 +968,24 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
         // replay, oldest first; entry 0 is this record
         bool have = false, keep_me = true;
         uint32_t busy = 0;
-        for (int k = ns - 1; k >= 0; k--) {
-            const bool drop = have && trig[k] <= busy;
-            if (!drop) { have = true; busy = endc[k]; }
-            if (k == 0) keep_me = !drop;
+        if (!full) {
+            for (int k = ns - 1; k >= 0; k--) {
+                const bool drop = have && trig[k] <= busy;
+                if (!drop) { have = true; busy = endc[k]; }
+                if (k == 0) keep_me = !drop;
+            }
+        } else {
+            // more candidates can matter than the set holds (dense false syncs over several lanes): the rule itself,
+            // sequentially over every record of the channel up to this one -- exact, and only ever this slow here
+            for (uint32_t g2 = g_first; g2 <= g; g2++) {
+                const uint32_t c2 = g2 == g ? i + 1u : (lane_cnt[g2] < K ? lane_cnt[g2] : K);
+                for (uint32_t i2 = 0; i2 < c2; i2++) {
+                    const uint32_t* r = reinterpret_cast<const uint32_t*>(&stage[(size_t)g2 * K + i2].bytes[128]);
+                    const bool drop = have && r[0] <= busy;
+                    if (!drop) { have = true; busy = r[1]; }
+                    if (g2 == g && i2 == i) keep_me = !drop;
+                }
+            }
         }
         if (stage[(size_t)g * K + i].sample_index < min_index) keep_me = false;
         stage[(size_t)g * K + i].pdu_type = keep_me ? 0 : 1;

@@ -194,3 +194,28 @@ def test_lanes_against_one_lane_on_a_noisy_wideband_capture():
         assert lost + extra <= 0.02 * len(one_ok), (core, lost, extra)
         assert abs(len(ok) - len(one_ok)) <= 0.01 * len(one_ok)
         assert missing(one_bad, bad) + missing(bad, one_bad) <= 2
+
+
+@pytest.mark.parametrize("cfo_hz,sigma", [(0.0, 0.0), (50e3, 0.02), (100e3, 0.02), (50e3, 0.1)])
+def test_one_clean_802154_channel_through_the_16_channel_prototype(cfo_hz, sigma):
+    """the M = 16 prototype's 0.9 MHz cutoff was chosen on the synthetic all-bins raster.  Loopback on
+    something else: ONE 2 Mchip/s O-QPSK channel alone in the band (no neighbours), with carrier offsets up to
+    +-100 kHz and noise: the wideband path must find what the narrowband receiver finds on the same 4 Msps stream
+    before it was put on the bin (the filter costs the wanted signal nothing it needs)."""
+    from snout_amd.rx import SnoutRx
+    b, seed, n_ch = 5, 21, 1 << 19
+    x, truth = synth.wideband_capture(1, 8 * n_ch, seed=seed, bins=[b], sigma=sigma, cfo_max_hz=cfo_hz, slotted=False)
+    nb, tr = synth.zigbee_capture(n_ch, channel=synth.zigbee_bin_channel(b), seed=seed * 1000 + b, noise=False,
+                                  cfo_max_hz=cfo_hz, slot_phase=None)
+    assert [t.payload for t in tr] == [t.payload for t in truth] and len(truth) > 20
+    with SnoutRx(proto=1, n_channels=16) as rx:
+        wide = rx.process(x)
+    with SnoutRx(proto=1, channel=synth.zigbee_bin_channel(b)) as rx:
+        narrow = rx.process(nb)                                       # the clean narrowband stream: what there is to find
+    sent = {t.payload for t in truth}
+    ok_w = {bytes(p["bytes"][:p["len"]]) for p in wide if p["crc_ok"] and p["channel"] == synth.zigbee_bin_channel(b)}
+    ok_n = {bytes(p["bytes"][:p["len"]]) for p in narrow if p["crc_ok"]}
+    assert ok_w <= sent and ok_n <= sent
+    assert len(ok_n) >= 0.97 * len(sent)
+    assert len(ok_w) >= (0.97 if sigma <= 0.02 else 0.93) * len(ok_n), (len(ok_w), len(ok_n), len(sent))
+    assert not [p for p in wide if p["crc_ok"] and p["channel"] != synth.zigbee_bin_channel(b)]     # nothing leaks into other bins
