@@ -177,6 +177,9 @@ struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
     uint32_t grid_blocks = 0;        // persistent grid; 0 = what is RESIDENT at once (see PfbCtx::run), else SNOUT_PFB_BLOCKS
+    bool last_spec = false;          // the last launch was a pfb_spec.hip kernel (profile names)
+    uint32_t small_tiles = 0;        // SNOUT_PFB_SMALL40 / SNOUT_PFB_SMALL16: launches with fewer tiles than this use pfb.hip's kernels (several workgroups per CU
+                                     // leave room for other streams' kernels; pfb_spec.hip's one 16-wave workgroup per CU does not)
     int impl = 4;                    // SNOUT_PFB_IMPL, M = 40 kernel: 0 valu = pfb.hip, 1 mfma / 2 spec16 = pfb_mfma.hip with its FIR on the matrix / vector pipe, 3 spec12 / 4 spec = pfb_spec.hip with 12 / 16 waves
     DevBuf d_proto, d_tw, d_tw5, d_y;
     int init(uint32_t M);

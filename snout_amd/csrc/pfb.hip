@@ -755,6 +755,7 @@ int PfbCtx::init(uint32_t M_)
     M = M_;
     if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
     if (const char* e = getenv("SNOUT_PFB_IMPL")) impl = strcmp(e, "valu") == 0 ? 0 : (strcmp(e, "mfma") == 0 ? 1 : (strcmp(e, "spec16") == 0 ? 2 : (strcmp(e, "spec12") == 0 ? 3 : 4)));
+    if (const char* e = getenv(M_ == 40 ? "SNOUT_PFB_SMALL40" : "SNOUT_PFB_SMALL16")) small_tiles = (uint32_t)atoi(e);
     if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
     const float* proto = M == 40 ? kPfbProto40 : kPfbProto16;
     const float* tw = M == 40 ? kTw40 : kTw16;
@@ -820,7 +821,9 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     // them per CU, not the three that 16 slots / 5 waves suggests (census with s_memrealtime stamps,
     // tools/pfb_stamps.py: 512 of 768 workgroups started at once, 2 on every CU, the other 256 after
     // them; a 514-workgroup grid takes 5.9 ms instead of 3.8).
-    if (M == 40 && impl != 0) {
+    const bool small = (uint64_t)cdiv(n_out, 128u) * count < small_tiles;      // tiles of the whole launch
+    last_spec = impl != 0 && !small && (M == 16 || impl >= 3);
+    if (M == 40 && impl != 0 && !small) {
         // pfb_mfma.hip: one 16-wave workgroup per CU (FIR on the matrix pipe beside the FFT waves), tiles of 128
         const uint32_t n_tiles = cdiv(n_out, 128u);
         const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
@@ -839,7 +842,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
             SNOUT_PFB(40, true, (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
         else
             SNOUT_PFB(40, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
-    } else if (impl != 0) {
+    } else if (impl != 0 && !small) {
         // pfb_spec.hip, M = 16: FIR waves beside FFT + discriminator waves, one 16-wave workgroup per CU
         const uint32_t n_tiles = cdiv(n_out, 128u);
         const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);

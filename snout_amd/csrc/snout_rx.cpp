@@ -683,9 +683,9 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     out->n_hits = s.h_totals[0];
     out->dominant_launches = 1;
     if (h->wide) {
-        if (h->pfb.impl != 0 && (h->pfb.M == 16 || h->pfb.impl >= 3))       // which kernel PfbCtx::run_batch launches
+        if (h->pfb.last_spec)                            // which kernel PfbCtx::run_batch launched
             snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_spec%u", h->pfb.M);
-        else if (h->pfb.impl != 0)
+        else if (h->pfb.impl != 0 && h->pfb.M == 40 && h->pfb.impl < 3)
             snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_mfma<40>");
         else
             snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);

@@ -12,8 +12,8 @@ rows = list(csv.DictReader(open(f)))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("snout::", "")[:28], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows]
 ev.sort()
 # the timed region: the last 6 steps = the last 6 x 48 launches of the 40-channel channelizer
-p40 = [e[0] for e in ev if e[2].startswith("void pfb_channelize<40")]
-lo = p40[-(len(p40) * 6 // 9)]
+p40 = [e[0] for e in ev if e[2].startswith("void pfb_channelize<40") or e[2].startswith("void pfb_spec<40")]
+lo = p40[-(len(p40) * 6 // 11)]
 ev = [e for e in ev if e[0] >= lo]
 span = max(e[1] for e in ev) - min(e[0] for e in ev)
 pts = []
