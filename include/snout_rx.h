@@ -91,6 +91,12 @@ typedef struct snout_rx_cfg {
     uint32_t reserved[1];     /* zero                                                            */
 } snout_rx_cfg;
 
+/* snout_pkt.flags of an 802.15.4 record: the clock recovery runs in lanes (cfg.zb_core); where one lane's timing
+ * loop hands over to the next INSIDE this frame, the two loops had decided some of the frame's last 48 chips before
+ * the hand-over differently -- the frame's chips depend on which loop is asked, so the reference's one sequential
+ * loop may have decided this frame differently too.  Never set with one lane per channel. */
+#define SNOUT_PKT_ZB_SEAM_DISAGREED 0x04u
+
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
 typedef struct snout_pkt {
     uint64_t sample_index;    /* BTLE: first sample of the access address; Zigbee: window start of the
@@ -105,7 +111,7 @@ typedef struct snout_pkt {
     uint8_t  crc_ok;          /* BTLE: 1 if CRC24 matches (btle_rx prints CRC0). Zigbee: FCS-16 ok */
     uint8_t  lqi;             /* Zigbee LQI as packet_sink computes it; BTLE 0                   */
     uint8_t  pdu_type;        /* BTLE header & 0x0F                                              */
-    uint8_t  flags;           /* BTLE: TxAdd | RxAdd<<1                                          */
+    uint8_t  flags;           /* BTLE: TxAdd | RxAdd<<1.  Zigbee: SNOUT_PKT_ZB_SEAM_DISAGREED              */
     uint32_t aux;             /* BTLE: sample phase 0..3 of the hit; Zigbee: lane id             */
     uint8_t  bytes[136];
 } snout_pkt;

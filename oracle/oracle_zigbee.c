@@ -384,6 +384,10 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
     return lp_in;
 }
 
+/* Developer aid (tools/ only): when set, channel_lanes copies its stitched chip stream, the chips' window starts and the
+ * lanes' first owned chips here. */
+uint8_t* g_dbg_bits = NULL; uint64_t* g_dbg_pos = NULL; uint64_t* g_dbg_first = NULL; uint64_t g_dbg_cap = 0, g_dbg_n = 0, g_dbg_lanes = 0;
+
 /* One channel: lanes -> stitched chip stream -> lane-local sinks. */
 static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint32_t channel,
                           uint32_t threshold, uint32_t core, uint32_t warmup,
@@ -398,12 +402,14 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
     uint8_t* sb = (uint8_t*)malloc(n + 16);             /* stitched stream: at most one chip per sample */
     uint64_t* spos = (uint64_t*)malloc((n + 16) * 8);
     uint64_t* o = (uint64_t*)malloc((n_lanes + 1) * 8); /* stream offset of every lane's first owned chip */
+    uint64_t* seam = (uint64_t*)malloc((n_lanes + 1) * 8); /* per lane: XOR of its 48 chips before the seam with lane l-1's last 48 (bit 0 = the last chip) */
     uint64_t total = 0;
     uint64_t E = 0, prev_nc = 0, prev_hist = 0;
     for (uint64_t l = 0; l < n_lanes; l++) {
         const uint64_t cs = l * core, ce = cs + core;
         const uint64_t nc = mm_lane(d, n, cs, core, warmup, lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
         uint64_t f = 0;
+        seam[l] = l ? 0xFFFFFFFFFFFFull : 0;                        /* no comparison made: nothing verified */
         if (l > 0) {
             uint64_t c0 = 0;
             while (c0 < nc && lpos[c0] + 3 < cs) c0++;              /* first candidate */
@@ -423,7 +429,7 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
                     if (e < 47 || e > (int64_t)c_end) continue;
                     const uint64_t own = (H >> (c_end - (uint64_t)e)) & 0xFFFFFFFFFFFFull;
                     const int agree = 48 - __builtin_popcountll(own ^ (prev_hist & 0xFFFFFFFFFFFFull));
-                    if (agree > best) { best = agree; f = (uint64_t)((int64_t)f0 + shifts[k]); }
+                    if (agree > best) { best = agree; f = (uint64_t)((int64_t)f0 + shifts[k]); seam[l] = own ^ (prev_hist & 0xFFFFFFFFFFFFull); }
                 }
             }
         }
@@ -435,13 +441,26 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         for (uint64_t j = (nc >= 64 ? nc - 64 : 0); j < nc; j++) prev_hist = (prev_hist << 1) | lb[j];
     }
     o[n_lanes] = total;
+    if (g_dbg_bits) {
+        g_dbg_n = total < g_dbg_cap ? total : g_dbg_cap;
+        memcpy(g_dbg_bits, sb, g_dbg_n); memcpy(g_dbg_pos, spos, g_dbg_n * 8);
+        g_dbg_lanes = n_lanes;
+        if (g_dbg_first) memcpy(g_dbg_first, o, (n_lanes + 1) * 8);
+    }
     uint64_t busy_end = 0;          /* last chip of the frame kept last (sequential rule) */
     int have_kept = 0;
     for (uint64_t l = 0; l < n_lanes; l++) {
         lane_t s;
         memset(&s, 0, sizeof(s));
         enter_search(&s);
-        for (uint64_t q = o[l] > ORACLE_ZB_SINK_WARM ? o[l] - ORACLE_ZB_SINK_WARM : 0; q < total; q++) {
+        uint64_t q_start = o[l] > ORACLE_ZB_SINK_WARM ? o[l] - ORACLE_ZB_SINK_WARM : 0;
+        /* ANALYSIS SWITCH (tools/lane_residual.py; never set in tests or by the product's parity runs): the sequential
+         * sink is busy with the frame kept last until its last chip and searches again, register cleared, from the
+         * next one; a lane's sink that starts inside that frame can false-sync on payload symbols, and a phantom's
+         * bogus length can run over the next real frame.  With the switch the lane's sink starts behind the kept
+         * frame instead: what that rule would recover of the lanes' residual. */
+        if (getenv("ORACLE_ZB_EXPERIMENT_RESTART") != NULL && have_kept && q_start <= busy_end) q_start = busy_end + 1;
+        for (uint64_t q = q_start; q < total; q++) {
             if (s.state == 0 && s.preamble_cnt == 0 && q >= o[l + 1]) break;   /* idle past the lane */
             const int done = sink_chip(&s, sb[q] ? 1.0f : -1.0f, q, threshold);  /* trigger = chip index */
             /* a frame belongs to the lane that owns the chip completing its SFD: sinks may first
@@ -462,6 +481,17 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
                     unsigned scaled = (s.lqi / 8) << 3;
                     p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
                     p->aux = (uint32_t)l;
+                    /* SNOUT_PKT_ZB_SEAM_DISAGREED.  Seams inside the frame = hand-overs from one lane's timing loop to
+                     * the next between the trigger chip and the last chip.  The two loops ran side by side over the 48
+                     * chips before the seam (seam[m]: XOR of their decisions, bit 0 = the last chip before it); if they
+                     * decided any of those that belong to the frame differently, the frame's chips depend on which
+                     * loop is asked -- the one sequential loop's may differ too. */
+                    for (uint64_t m = 1; m < n_lanes; m++) {
+                        if (o[m] <= s.trigger || o[m] > q) continue;
+                        const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
+                        const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
+                        if (seam[m] & mask) p->flags |= 4u;
+                    }
                     memcpy(p->bytes, s.pkt, (size_t)s.packetlen_cnt);
                     if (s.packetlen_cnt >= 3) {
                         uint16_t c = oracle_crc16_154(s.pkt, s.packetlen_cnt - 2);
@@ -474,7 +504,7 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
             }
         }
     }
-    free(o); free(spos); free(sb); free(lkey); free(lpos); free(lb); free(lp_in);
+    free(seam); free(o); free(spos); free(sb); free(lkey); free(lpos); free(lb); free(lp_in);
 }
 
 int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,

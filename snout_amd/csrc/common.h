@@ -224,6 +224,7 @@ struct ZbCtx {
     int enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
                       bool time_front, int fmt = 0);
     PfbZbTarget pfb_target(uint32_t seg = 0) const;
+    unsigned long long* seam_masks() const;         // per lane: XOR of the two timing loops' last 48 chips before its seam
     int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s, bool time_front);
     bool check_overflow(const ResultSlot& s);
     int soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64_t cap, uint64_t* n_out);

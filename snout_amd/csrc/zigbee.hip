@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256) void zb_stitch(const ZbLaneOut* __restrict__ l
                                                  const uint32_t* __restrict__ cand_keys,
                                                  uint32_t lanes_per_slot, uint32_t core, uint32_t warmup,
                                                  uint32_t tiles_per_slot, uint32_t* __restrict__ first_owned,
-                                                 uint32_t* __restrict__ owned, uint32_t* __restrict__ tsum)
+                                                 uint32_t* __restrict__ owned, uint32_t* __restrict__ tsum,
+                                                 unsigned long long* __restrict__ seam)
 {
     __shared__ uint32_t lds4[4];
     const uint32_t slot = blockIdx.y, tile = blockIdx.x;
@@ -392,6 +393,9 @@ __global__ __launch_bounds__(256) void zb_stitch(const ZbLaneOut* __restrict__ l
         const uint32_t g = slot * lanes_per_slot + li;
         const ZbLaneOut me = lane_out[g];
         uint32_t f = 0;
+        // XOR of this lane's 48 chips before the seam with the last 48 of the lane before it (bit 0 = the last chip):
+        // what zb_resolve flags frames by (oracle: seam[]); all ones = no comparison was made
+        unsigned long long sd = li > 0u ? 0xFFFFFFFFFFFFull : 0ull;
         if (li > 0u) {
             const ZbLaneOut pv = lane_out[g - 1u];
             const uint64_t cs = (uint64_t)li * core;
@@ -414,11 +418,12 @@ __global__ __launch_bounds__(256) void zb_stitch(const ZbLaneOut* __restrict__ l
                     if (e < 47 || e > (int64_t)c_end) continue;
                     const uint64_t own = (me.hist_cand >> (c_end - (uint32_t)e)) & m48;
                     const int agree = 48 - __popcll(own ^ (pv.hist_end & m48));
-                    if (agree > best) { best = agree; f = (uint32_t)((int64_t)f0 + sft); }
+                    if (agree > best) { best = agree; f = (uint32_t)((int64_t)f0 + sft); sd = own ^ (pv.hist_end & m48); }
                 }
             }
         }
         if (f > me.nc) f = me.nc;
+        seam[g] = sd;
         first_owned[g] = f;
         owned[g] = me.nc - f;
         s += me.nc - f;
@@ -925,6 +930,7 @@ constexpr int kResolveSet = 48;
 __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage, const uint32_t* __restrict__ lane_cnt,
                                                   uint32_t K, uint32_t lanes_per_slot, uint32_t total_lanes,
                                                   const uint32_t* __restrict__ offs, SegBatch segs,
+                                                  const unsigned long long* __restrict__ seam,
                                                   uint32_t* __restrict__ lane_kept)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -989,6 +995,23 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
         }
         if (stage[(size_t)g * K + i].sample_index < min_index) keep_me = false;
         stage[(size_t)g * K + i].pdu_type = keep_me ? 0 : 1;
+        // SNOUT_PKT_ZB_SEAM_DISAGREED: a seam inside the frame (trigger chip < the lane's first owned chip <= last chip)
+        // before which the two timing loops decided a chip of the frame differently (oracle_zigbee.c, same rule).
+        // The frame's SFD chip is in this lane: seams before it are those of lanes g, g - 1, ..., seams behind it g + 1, ...
+        {
+            const uint32_t T = me[0], E = me[1];
+            const uint32_t g_last = g_first + lanes_per_slot - 1u;
+            bool bad = false;
+            for (uint32_t m = g; m > g_first && offs[m] > T; m--) {
+                const uint32_t inside = offs[m] - T;
+                if (offs[m] <= E && (seam[m] & (inside >= 48u ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull)))) bad = true;
+            }
+            for (uint32_t m = g + 1u; m <= g_last && offs[m] <= E; m++) {
+                const uint32_t inside = offs[m] - T;
+                if (offs[m] > T && (seam[m] & (inside >= 48u ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull)))) bad = true;
+            }
+            if (bad) stage[(size_t)g * K + i].flags |= 4u;
+        }
         kept += keep_me ? 1u : 0u;
     }
     lane_kept[g] = kept;
@@ -1140,7 +1163,8 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
     if (int rc = d_lane_out.ensure((uint64_t)total_lanes * 32u)) return rc;
     if (int rc = d_cand.ensure((uint64_t)total_lanes * 12u * 4u)) return rc;
     // first_owned | owned | offs | tsum | slot_total
-    if (int rc = d_lane_u32.ensure(((uint64_t)total_lanes * 3u + (uint64_t)tiles_per_slot * n_slots + n_slots) * 4u)) return rc;
+    // first_owned | owned | offs | tsum | slot_total | (8-byte aligned) seam masks, one u64 per lane
+    if (int rc = d_lane_u32.ensure(((uint64_t)total_lanes * 3u + (uint64_t)tiles_per_slot * n_slots + n_slots + 2u) * 4u + (uint64_t)total_lanes * 8u)) return rc;
     if (int rc = d_stream.ensure(stream_words * n_slots * 8u * 2u)) return rc;     // chips | match masks
     if (int rc = d_stage.ensure((uint64_t)total_lanes * pkts_per_lane * sizeof(snout_pkt))) return rc;
     if (int rc = d_lane_cnt.ensure(2u * ((uint64_t)total_lanes + 1024u) * 4u)) return rc;     // raw counts, kept counts
@@ -1171,6 +1195,7 @@ int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
     uint32_t* offs = owned + total_lanes;
     uint32_t* tsum = offs + total_lanes;
     uint32_t* slot_total = tsum + (uint64_t)tiles_per_slot * n_slots;
+    unsigned long long* seam = seam_masks();
     {
         const uint64_t n16 = stream_words * n_slots / 2u;             // stream_words is even
         hipLaunchKernelGGL(zb_clear, dim3((uint32_t)std::min<uint64_t>(cdiv(n16, 256), 4096u)), dim3(256), 0, st,
@@ -1178,7 +1203,7 @@ int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
     }
     hipLaunchKernelGGL(zb_stitch, dim3(tiles_per_slot, n_slots), dim3(256), 0, st,
                        d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(), lanes_per_slot, core, warmup,
-                       tiles_per_slot, first_owned, owned, tsum);
+                       tiles_per_slot, first_owned, owned, tsum, seam);
     hipLaunchKernelGGL(zb_offsets, dim3(tiles_per_slot, n_slots), dim3(256), 0, st, owned, tsum,
                        lanes_per_slot, tiles_per_slot, offs, slot_total);
     hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
@@ -1273,6 +1298,12 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
     return 0;
 }
 
+unsigned long long* ZbCtx::seam_masks() const
+{
+    const uint64_t words = (uint64_t)total_lanes * 3u + (uint64_t)tiles_per_slot * n_slots + n_slots;
+    return reinterpret_cast<unsigned long long*>(d_lane_u32.as<uint32_t>() + ((words + 1u) & ~1ull));
+}
+
 PfbZbTarget ZbCtx::pfb_target(uint32_t seg) const
 {
     return PfbZbTarget{d_d.as<float>() + (uint64_t)seg * seg_slots * d_stride, d_stride,
@@ -1300,7 +1331,7 @@ int ZbCtx::enqueue_tail(uint64_t n, const SegBatch& segs_in, hipStream_t st, Res
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
     uint32_t* lane_kept = d_lane_cnt.as<uint32_t>() + total_lanes + 1024u;
     hipLaunchKernelGGL(zb_resolve, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_stage.as<snout_pkt>(),
-                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, lanes_per_slot, total_lanes, d_lane_u32.as<uint32_t>() + 2u * (uint64_t)total_lanes, segs, lane_kept);
+                       d_lane_cnt.as<uint32_t>(), pkts_per_lane, lanes_per_slot, total_lanes, d_lane_u32.as<uint32_t>() + 2u * (uint64_t)total_lanes, segs, seam_masks(), lane_kept);
     launch_tile_reduce(lane_kept, nullptr, total_lanes, total_lanes, pkts_per_lane,
                        sums, over, n_tiles, st);
     hipLaunchKernelGGL(zb_emit, dim3(n_tiles), dim3(256), 0, st, d_stage.as<snout_pkt>(),
