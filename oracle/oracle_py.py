@@ -204,10 +204,19 @@ def zb_discrim(iq: np.ndarray) -> np.ndarray:
     return d[:n]
 
 
-def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 2048,
-                   warmup: int = 512, first_sample_index: int = 0, cap: int = 0) -> np.ndarray:
+def zb_auto_shape(total_channel_samples: int):
+    """The product's default lane shape (ZbCtx::reserve, cfg.zb_core = cfg.zb_warmup = 0): by the size of the call."""
+    return (4096, 512) if total_channel_samples >= (1 << 29) else (2048, 512)
+
+
+def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 0,
+                   warmup: int = 0, first_sample_index: int = 0, cap: int = 0) -> np.ndarray:
+    """core = warmup = 0: the product's default (by the size of the call); core alone: warm-up 512."""
     a = _f32(iq)
     n = a.size // 2
+    if core == 0 and warmup == 0:
+        core, warmup = zb_auto_shape(n)
+    core, warmup = core or 2048, warmup or 512
     cap = cap or max(64, n // 512)
     out = np.zeros(cap, dtype=PKT_DTYPE)
     n_out = C.c_uint64(0)
@@ -260,10 +269,13 @@ def zigbee_bin_channel(b: int) -> int:
 
 
 def wideband_segment(iq: np.ndarray, proto: int, first_sample_index: int = 0, aa: int = 0x8E89BED6,
-                     crc_init: int = 0x555555, threshold: int = 10, core: int = 2048,
-                     warmup: int = 512, cap: int = 0) -> np.ndarray:
+                     crc_init: int = 0x555555, threshold: int = 10, core: int = 0,
+                     warmup: int = 0, cap: int = 0) -> np.ndarray:
     a = _f32(iq)
     n = a.size // 2
+    if proto == 1 and core == 0 and warmup == 0:        # the product's default: by channels x channel samples of the call
+        core, warmup = zb_auto_shape(16 * pfb_nout(n, 16))
+    core, warmup = core or 2048, warmup or 512
     cap = cap or max(256, n // 128)
     out = np.zeros(cap, dtype=PKT_DTYPE)
     n_out = C.c_uint64(0)

@@ -25,7 +25,7 @@ EXPORTS = [
     "snout_rx_profile_history", "snout_btle_format_line", "snout_rftap_encap",
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
     "snout_strerror", "snout_last_error", "snout_abi_version", "snout_bench_hbm_read_gbps",
-    "snout_rx_pack_last_records", "snout_rx_submit_batch_dev", "snout_rx_poll",
+    "snout_rx_pack_last_records", "snout_rx_submit_batch_dev", "snout_rx_poll", "snout_zigbee_lane_shape",
 ]
 
 

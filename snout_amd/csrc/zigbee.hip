@@ -1115,10 +1115,7 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
         for (int m = 0; m < 64; m++) { w[m] = v; v = v * one_minus; }
         for (int m = 0; m < 64; m++) p = p * one_minus;
         d64 = p;
-        dcore = 1.0;
-        for (uint32_t k = 0; k < core / 64u; k++) dcore = dcore * d64;
-        dfirst = 1.0;
-        for (uint32_t k = 0; k < (core - warmup) / 64u; k++) dfirst = dfirst * d64;
+        set_shape(core, warmup);
         if (int rc = d_iirw.ensure(64 * 8)) return rc;
         SNOUT_HIP(hipMemcpy(d_iirw.p, w, 64 * 8, hipMemcpyHostToDevice));
     }
@@ -1140,10 +1137,27 @@ void ZbCtx::destroy()
     d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
 }
 
+// Lane shape and the block decay factors of the IIR carry-in that depend on it.
+void ZbCtx::set_shape(uint32_t core_, uint32_t warmup_)
+{
+    core = core_;
+    warmup = warmup_;
+    dcore = 1.0;
+    for (uint32_t k = 0; k < core / 64u; k++) dcore = dcore * d64;
+    dfirst = 1.0;
+    for (uint32_t k = 0; k < (core - warmup) / 64u; k++) dfirst = dfirst * d64;
+}
+
 int ZbCtx::reserve(uint64_t n, uint32_t segs)
 {
     if (segs == 0 || segs > batch_cap) { set_last_error("batch of %u segments (handle created for %u)", segs, batch_cap); return SNOUT_EINVAL; }
     n_slots = seg_slots * segs;                     // slot = (segment of the batch, channel)
+    if (auto_shape) {
+        // cfg.zb_core = cfg.zb_warmup = 0: by the size of the call (snout_zigbee_lane_shape; oracle_py.zb_auto_shape mirrors it)
+        uint32_t c_ = 0, w_ = 0;
+        snout_zigbee_lane_shape(n * (uint64_t)n_slots, &c_, &w_);
+        set_shape(c_, w_);
+    }
     lanes_per_slot = cdiv(n, core);
     total_lanes = lanes_per_slot * n_slots;
     n_waves = cdiv(total_lanes, 64);

@@ -118,3 +118,16 @@ int main(void) {
             _ffi.RxCfg.sample_format.offset, _ffi.RxCfg.batch_segments.offset, _ffi.RxCfg.reserved.offset,
             _ffi.PKT_DTYPE.itemsize]
     assert got == want == [64, 44, 48, 52, 56, 60, 160]
+
+
+def test_lane_shape_rule_is_the_oracles():
+    """The default 802.15.4 lane shape depends on the size of the call; the checker (oracle_py.zb_auto_shape) must
+    run the shape the product runs."""
+    from snout_amd import _ffi
+    from oracle import oracle_py
+    lib = _ffi.load()
+    for total in (0, 1, 1 << 20, (1 << 29) - 1, 1 << 29, (1 << 29) + 1, 10 ** 9, 1 << 40):
+        c, w = C.c_uint32(0), C.c_uint32(0)
+        lib.snout_zigbee_lane_shape(C.c_uint64(total), C.byref(c), C.byref(w))
+        assert (c.value, w.value) == oracle_py.zb_auto_shape(total), total
+    assert oracle_py.zb_auto_shape(16 * 40_000_000) == (4096, 512) and oracle_py.zb_auto_shape(16 * (1 << 21)) == (2048, 512)

@@ -111,7 +111,7 @@ def test_rftap_datagrams_through_scan():
 
 
 @pytest.mark.parametrize("core,warmup", [(1024, 64), (1024, 960), (2048, 256), (8192, 512),
-                                          (4096, 2048), (16384, 4096)])
+                                          (4096, 2048), (16384, 4096), (4096, 1024)])
 def test_lane_shapes_match_oracle(oracle, core, warmup):
     """Every (core, warm-up) shape the ABI accepts: candidate tile, stitch and tail tile move with them."""
     n = (1 << 18) + 4321

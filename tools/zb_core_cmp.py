@@ -23,7 +23,7 @@ for rep in (4, 24, 238):
     del x
 tile, truth = synth.wideband_capture(1, 16 * (1 << 17), seed=4, sigma=0.0)
 t = torch.from_numpy(tile.view(np.float32)).cuda()
-for rep in (8, 64):
+for rep in (8, 64, 152):
     x = t.repeat(rep); x += 0.05 * torch.randn_like(x)
     for core in (4096, 2048):
         rx = SnoutRx(proto=1, n_channels=16, zb_core=core)
