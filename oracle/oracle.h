@@ -43,6 +43,9 @@ int      oracle_zigbee_lane_soft(const float* iq, uint64_t n, uint32_t core, uin
 uint64_t oracle_pfb_nout(uint64_t n, uint32_t M);
 const float* oracle_pfb_proto(uint32_t M);
 int      oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride);
+/* the same sums in the term order of the experimental matrix-pipe FIR (snout_amd/csrc/pfb_mfma.hip); differs from
+ * oracle_pfb only for non-finite samples and results that are zero */
+int oracle_pfb_block_order(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride);
 uint32_t oracle_btle_bin_channel(uint32_t bin);
 uint32_t oracle_zigbee_bin_channel(uint32_t bin);
 int      oracle_wideband_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t proto,

@@ -9,8 +9,7 @@
  *
  * Definition (M channels, decimation D = M/2, P = 16 taps per branch, L = M P, prototype h):
  *   u_m[r] = sum_{p=0}^{P-1} h[r + pM] x[mD + r + pM]         fmaf chain over ascending p
- *            M = 40: the chain as the matrix pipe runs it (fir40_block_order below): identical to the
- *            16-term chain except for non-finite samples and results that are zero
+ *            (oracle_pfb_block_order: the same sum in the term order of the experimental matrix-pipe kernel)
  *   X_m[k] = sum_r u_m[r] e^{-2 pi i k r / M}                  two-factor FFT specified below
  *   y_k[m] = (-1)^{k m} X_m[k]                                 (D = M/2 phase rotation)
  * for m = 0 .. n_out-1, n_out = (n - L)/D + 1.  y_k is channel k (centre k fs/M) at 2 fs/M.
@@ -131,16 +130,17 @@ uint64_t oracle_pfb_nout(uint64_t n, uint32_t M)
 
 const float* oracle_pfb_proto(uint32_t M) { return M == 40 ? kPfbProto40 : (M == 16 ? kPfbProto16 : NULL); }
 
-/* The M = 40 FIR in the term order of the product's matrix-pipe kernel (snout_amd/csrc/pfb_mfma.hip).
- * There the 128 output times of a tile are, per branch r and output parity e, four blocks of 16
- * consecutive outputs idx = 16 b + j of the stream z[q] = x[128 D tile + q M + e D + r]; a block is ONE
- * product over the 32 window positions k = 0..31 with the banded Toeplitz matrix of the branch's taps:
+/* The M = 40 FIR in the term order of the EXPERIMENTAL matrix-pipe kernel (snout_amd/csrc/pfb_mfma.hip, selected with
+ * SNOUT_PFB_IMPL=mfma; the shipped kernel pfb_spec.hip runs the 16-term chain above).  There the 128 output times of a
+ * tile are, per branch r and output parity e, four blocks of 16 consecutive outputs idx = 16 b + j of the stream
+ * z[q] = x[128 D tile + q M + e D + r]; a block is ONE product over the 32 window positions k = 0..31 with the banded
+ * Toeplitz matrix of the branch's taps:
  *     u = fmaf(z[16 b + k], t, u)  for ascending k,   t = h[r + (k - j) M] if 0 <= k - j < 16, else +0,
- * the operand of k = 31 (no output has a tap there) being +0 instead of a sample; samples past the end
- * of the segment read as +0.  A zero tap contributes (sample x 0) = +-0, which leaves a non-zero finite
- * sum untouched, so this equals the 16-term chain unless a sample of the window is not finite (NaN / Inf
- * x 0 = NaN reaches all 16 outputs of the block) or the result is a zero (whose sign the +-0 terms can
- * change).  oracle_pfb() therefore runs the 16-term chain and comes here in exactly those two cases. */
+ * the operand of k = 31 (no output has a tap there) being +0 instead of a sample; samples past the end of the segment
+ * read as +0.  A zero tap contributes (sample x 0) = +-0, which leaves a non-zero finite sum untouched, so this equals
+ * the 16-term chain unless a sample of the window is not finite (NaN / Inf x 0 = NaN reaches all 16 outputs of the
+ * block) or the result is a zero (whose sign the +-0 terms can change).  oracle_pfb_block_order() runs the 16-term
+ * chain and comes here in exactly those two cases. */
 static void fir40_block_order(const float* iq, uint64_t n, uint64_t m, uint32_t r, const float* h, float* re, float* im)
 {
     const uint32_t M = 40, D = 20, T = 128;
@@ -159,7 +159,12 @@ static void fir40_block_order(const float* iq, uint64_t n, uint64_t m, uint32_t 
 }
 
 /* y: [M][y_stride] interleaved complex floats (2 floats per sample) */
-int oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride)
+static int pfb_impl(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride, int block_order);
+int oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride) { return pfb_impl(iq, n, M, y, y_stride, 0); }
+/* the experimental matrix-pipe kernel's term order (M = 40 only differs) */
+int oracle_pfb_block_order(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride) { return pfb_impl(iq, n, M, y, y_stride, 1); }
+
+static int pfb_impl(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride, int block_order)
 {
     if (M != 40 && M != 16) return -1;
     const float* h = oracle_pfb_proto(M);
@@ -167,7 +172,7 @@ int oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_str
     const uint64_t n_out = oracle_pfb_nout(n, M);
     /* any sample that is not finite?  (exponent all ones; one pass, only the M = 40 term order cares) */
     int nonfinite = 0;
-    if (M == 40) {
+    if (M == 40 && block_order) {
         const uint32_t* w = (const uint32_t*)iq;
         uint32_t seen = 0;
 #pragma omp parallel for schedule(static) reduction(|:seen)
@@ -185,7 +190,7 @@ int oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_str
                 ar = fmaf(c, x[2 * (r + p * M)], ar);
                 ai = fmaf(c, x[2 * (r + p * M) + 1], ai);
             }
-            if (M == 40 && (nonfinite || ar == 0.0f || ai == 0.0f)) fir40_block_order(iq, n, (uint64_t)m, r, h, &ar, &ai);
+            if (M == 40 && block_order && (nonfinite || ar == 0.0f || ai == 0.0f)) fir40_block_order(iq, n, (uint64_t)m, r, h, &ar, &ai);
             u[r].re = ar; u[r].im = ai;
         }
         if (M == 40) fft40(u, X); else fft16(u, X);

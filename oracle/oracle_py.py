@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
         _lib.oracle_pfb_proto.restype = C.POINTER(C.c_float)
         _lib.oracle_pfb.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint64]
         _lib.oracle_pfb.restype = C.c_int
+        _lib.oracle_pfb_block_order.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint64]
+        _lib.oracle_pfb_block_order.restype = C.c_int
         _lib.oracle_btle_bin_channel.argtypes = [C.c_uint32]
         _lib.oracle_btle_bin_channel.restype = C.c_uint32
         _lib.oracle_zigbee_bin_channel.argtypes = [C.c_uint32]
@@ -249,13 +251,14 @@ def pfb_proto(M: int) -> np.ndarray:
     return np.array(lib().oracle_pfb_proto(M)[:M * 16], dtype=np.float32)
 
 
-def pfb(iq: np.ndarray, M: int) -> np.ndarray:
-    """-> complex64 [M, n_out]"""
+def pfb(iq: np.ndarray, M: int, block_order: bool = False) -> np.ndarray:
+    """-> complex64 [M, n_out].  block_order: the term order of the experimental matrix-pipe FIR (SNOUT_PFB_IMPL=mfma)."""
     a = _f32(iq)
     n = a.size // 2
     no = pfb_nout(n, M)
     y = np.zeros((M, max(no, 1) * 2), dtype=np.float32)
-    rc = lib().oracle_pfb(_p(a, C.c_float), n, M, _p(y, C.c_float), max(no, 1))
+    fn = lib().oracle_pfb_block_order if block_order else lib().oracle_pfb
+    rc = fn(_p(a, C.c_float), n, M, _p(y, C.c_float), max(no, 1))
     assert rc == 0
     return y.view(np.complex64)[:, :no]
 

@@ -31,6 +31,27 @@ def test_channelizer_bit_exact(oracle, M, proto, n):
             assert np.array_equal(got.view(np.uint32), want[slot].view(np.uint32)), slot
 
 
+@pytest.mark.parametrize("M,proto", [(40, 0), (16, 1)])
+def test_channelizer_with_non_finite_samples(oracle, M, proto):
+    """A NaN / Inf sample reaches exactly the outputs whose 16-tap windows hold it (the FIR is a plain chain per output);
+    everything else stays bit-identical -- also across tiles, workgroup ranges and the second FFT block of a tile."""
+    from snout_amd.rx import SnoutRx
+    n = M * 16 + (M // 2) * 3000 + 7
+    rng = np.random.default_rng(M)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for i, v in ((5, np.nan), (n // 3, np.inf), (n // 2 + 1, -np.inf), (n - 3, np.nan)):
+        x[i] = v
+    want = oracle.pfb(x, M)
+    with SnoutRx(proto=proto, n_channels=M, keep_channel_iq=True) as rx:
+        rx.process(x)
+        for slot in (0, 3, M - 1):
+            got = rx.soft(STAGE_CHAN_IQ, slot).view(np.complex64)
+            assert np.array_equal(np.isnan(got.view(np.float32)), np.isnan(want[slot].view(np.float32)))
+            ok = ~np.isnan(got.view(np.float32))
+            assert np.array_equal(got.view(np.uint32)[ok], want[slot].view(np.uint32)[ok]), slot
+    assert 0 < np.isnan(want[0].view(np.float32)).sum() < want[0].size        # the NaNs stayed local
+
+
 def test_channelizer_shorter_than_prototype():
     from snout_amd.rx import SnoutRx
     with SnoutRx(proto=0, n_channels=40) as rx:

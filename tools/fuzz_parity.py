@@ -56,7 +56,10 @@ def main(budget_s):
             n = int(rng.integers(640, 40 * 60000))
             x, _ = synth.wideband_capture(0, n, seed=seed, bins=sorted(rng.choice(40, 6, replace=False).tolist()),
                                           mean_gap=float(rng.choice([2000.0, 8000.0])))
-            xin, x = prep(x[:n])
+            x = x[:n]
+            if rng.random() < 0.2 and fmt == 0:             # non-finite samples: 16 taps' reach, nothing more
+                x[int(rng.integers(0, n))] = [np.nan, np.inf, -np.inf][int(rng.integers(3))]
+            xin, x = prep(x)
             with SnoutRx(proto=0, n_channels=40, sample_format=fmt) as rx:
                 got = rx.process(xin, first_sample_index=first)
             want = oracle.wideband_segment(x, 0, first_sample_index=first)
@@ -66,7 +69,10 @@ def main(budget_s):
             core = int(rng.choice([1024, 2048, 4096]))
             x, _ = synth.wideband_capture(1, n, seed=seed, bins=sorted(rng.choice(16, 4, replace=False).tolist()),
                                           mean_gap=float(rng.choice([3000.0, 12000.0])), max_len=40)
-            xin, x = prep(x[:n])
+            x = x[:n]
+            if rng.random() < 0.2 and fmt == 0:
+                x[int(rng.integers(0, n))] = [np.nan, np.inf, -np.inf][int(rng.integers(3))]
+            xin, x = prep(x)
             with SnoutRx(proto=1, n_channels=16, zb_core=core, sample_format=fmt) as rx:
                 got = rx.process(xin, first_sample_index=first)
             want = oracle.wideband_segment(x, 1, first_sample_index=first, core=core)
