@@ -386,9 +386,9 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     from snout_amd.sharded import ShardedScan, pump
     nb_rank, nz_rank = int(80e6 * seconds), int(32e6 * seconds)
     sb = ShardedScan(0, n_channels=40, seg_len=SEG, device=device.index, handles=int(os.environ.get("SNOUT_CFG5_HB", "1")),
-                     batch=int(os.environ.get("SNOUT_CFG5_BB", "4")))
+                     batch=int(os.environ.get("SNOUT_CFG5_BB", "6")))
     sz = ShardedScan(1, n_channels=16, seg_len=SEG, device=device.index, handles=int(os.environ.get("SNOUT_CFG5_HZ", "2")),
-                     batch=int(os.environ.get("SNOUT_CFG5_BZ", "4")))
+                     batch=int(os.environ.get("SNOUT_CFG5_BZ", "8")))
     # The virtual capture is N x `seconds` long and tile-periodic with a period that divides the
     # segment length, so every segment starts on a tile boundary: the overlap a rank reads behind its
     # segment i shows the same packets as the start of segment i+1 on the next rank (only the noise
