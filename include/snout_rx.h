@@ -215,7 +215,7 @@ int  snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap);
 /* Channel plans (a10). */
 double   snout_zigbee_center_hz(uint32_t channel);   /* 1e6*(2400+5*(ch-10)), top_block.py:56,94-96 */
 /* The 802.15.4 lane shape a handle with cfg.zb_core = cfg.zb_warmup = 0 uses for a call of `channel_samples`
- * (channels x channel samples of the call): the clock recovery (clock_recovery_mm_ff, top_block.py:69) runs in lanes of
+ * (channels x channel samples of one segment of the call): the clock recovery (clock_recovery_mm_ff, top_block.py:69) runs in lanes of
  * `core` samples that start `warmup` samples early; long calls get the longer shape.  Results are a function of the
  * shape, so a checker has to run the same one. */
 void     snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup);

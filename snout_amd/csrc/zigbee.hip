@@ -1155,7 +1155,7 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
     if (auto_shape) {
         // cfg.zb_core = cfg.zb_warmup = 0: by the size of the call (snout_zigbee_lane_shape; oracle_py.zb_auto_shape mirrors it)
         uint32_t c_ = 0, w_ = 0;
-        snout_zigbee_lane_shape(n * (uint64_t)n_slots, &c_, &w_);
+        snout_zigbee_lane_shape(n * (uint64_t)seg_slots, &c_, &w_);     // per segment: a batch decodes exactly what its segments decode one by one
         set_shape(c_, w_);
     }
     lanes_per_slot = cdiv(n, core);
