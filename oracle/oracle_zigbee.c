@@ -399,12 +399,56 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
     uint8_t* lb = (uint8_t*)malloc(lane_cap);
     uint64_t* lpos = (uint64_t*)malloc(lane_cap * 8);
     uint64_t* lkey = (uint64_t*)malloc(lane_cap * 8);
-    uint8_t* sb = (uint8_t*)malloc(n + 16);             /* stitched stream: at most one chip per sample */
-    uint64_t* spos = (uint64_t*)malloc((n + 16) * 8);
+    uint8_t* sb = (uint8_t*)malloc(n + 16 + 4096);      /* stitched stream: at most one chip per sample */
+    uint64_t* spos = (uint64_t*)malloc((n + 16 + 4096) * 8);
     uint64_t* o = (uint64_t*)malloc((n_lanes + 1) * 8); /* stream offset of every lane's first owned chip */
     uint64_t* seam = (uint64_t*)malloc((n_lanes + 1) * 8); /* per lane: XOR of its 48 chips before the seam with lane l-1's last 48 (bit 0 = the last chip) */
     uint64_t total = 0;
     uint64_t E = 0, prev_nc = 0, prev_hist = 0;
+    /* ANALYSIS SWITCH (tools/lane_residual.py only): verified hand-over.  Every lane runs P samples past its core end;
+     * the next lane takes over at the first chip from which R consecutive chips of both loops agree in value and in
+     * time (keys within half a sample), or at the end of the post-roll if they never do. */
+    const char* pr_env = getenv("ORACLE_ZB_EXPERIMENT_POSTROLL");
+    if (pr_env != NULL && atoi(pr_env) > 0) {
+        const uint64_t P = (uint64_t)atoi(pr_env);
+        const uint64_t R = getenv("ORACLE_ZB_EXPERIMENT_RUN") ? (uint64_t)atoi(getenv("ORACLE_ZB_EXPERIMENT_RUN")) : 48u;
+        const uint64_t cap2 = lane_cap + P;
+        uint8_t* pb = (uint8_t*)malloc(cap2); uint64_t* ppos = (uint64_t*)malloc(cap2 * 8); uint64_t* pkey = (uint64_t*)malloc(cap2 * 8);
+        uint8_t* cb = (uint8_t*)malloc(cap2); uint64_t* cpos = (uint64_t*)malloc(cap2 * 8); uint64_t* ckey = (uint64_t*)malloc(cap2 * 8);
+        uint64_t pnc = 0, pfrom = 0;
+        for (uint64_t l = 0; l < n_lanes; l++) {
+            const uint64_t cs = l * core;
+            const uint64_t nc = mm_lane(d, n, cs, core + P, warmup, lp_in[l], cb, cpos, ckey, NULL, NULL, 0);
+            uint64_t cfrom = 0;
+            seam[l] = 0;
+            if (l > 0) {
+                uint64_t c0 = 0;
+                while (c0 < nc && cpos[c0] + 3 < cs) c0++;
+                uint64_t i = pfrom, run = 0, last_i = 0, pto = pnc;
+                int found = 0;
+                for (uint64_t j = c0; j < nc; j++) {
+                    while (i < pnc && pkey[i] + 64 < ckey[j]) i++;
+                    if (i >= pnc) break;
+                    const int ok = pkey[i] <= ckey[j] + 64 && pb[i] == cb[j];
+                    if (ok && run > 0 && i == last_i + 1) run++; else run = ok ? 1 : 0;
+                    last_i = i;
+                    if (run >= R) { found = 1; pto = i + 1; cfrom = j + 1; break; }
+                }
+                if (!found) {
+                    seam[l] = 0xFFFFFFFFFFFFull;
+                    const uint64_t Ee = pnc ? pkey[pnc - 1] + 128u : cs * 128u;
+                    cfrom = c0;
+                    while (cfrom < nc && ckey[cfrom] < Ee) cfrom++;
+                }
+                o[l - 1] = total;
+                for (uint64_t j = pfrom; j < pto; j++) { sb[total] = pb[j]; spos[total] = ppos[j]; total++; }
+            }
+            { uint8_t* t8 = pb; pb = cb; cb = t8; uint64_t* t = ppos; ppos = cpos; cpos = t; t = pkey; pkey = ckey; ckey = t; }
+            pnc = nc; pfrom = cfrom;
+        }
+        if (n_lanes) { o[n_lanes - 1] = total; for (uint64_t j = pfrom; j < pnc; j++) { sb[total] = pb[j]; spos[total] = ppos[j]; total++; } }
+        free(pb); free(ppos); free(pkey); free(cb); free(cpos); free(ckey);
+    } else
     for (uint64_t l = 0; l < n_lanes; l++) {
         const uint64_t cs = l * core, ce = cs + core;
         const uint64_t nc = mm_lane(d, n, cs, core, warmup, lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
