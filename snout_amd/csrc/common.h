@@ -171,6 +171,7 @@ struct PfbMfArgs {
 int pfb_mfma_launch(uint32_t M, bool btle, int fmt, int impl, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // impl: 0 MFMA FIR, 1 VALU FIR
 
 // pfb_spec.hip: one workgroup of specialised waves per CU (FIR + staging | FFT in registers), M = 40 and 16
+uint32_t pfb_spec_tile(uint32_t M);      // output times per tile of the pfb_spec kernel for M channels
 int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // mode: 0 channel IQ, 1 BTLE planes, 2 802.15.4 rows; waves: 12 or 16 per workgroup (M = 40)
 
 struct PfbCtx {

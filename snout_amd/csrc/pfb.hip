@@ -844,13 +844,14 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
             SNOUT_PFB(40, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
     } else if (impl != 0 && !small) {
         // pfb_spec.hip, M = 16: FIR waves beside FFT + discriminator waves, one 16-wave workgroup per CU
-        const uint32_t n_tiles = cdiv(n_out, 128u);
+        const uint32_t T16 = pfb_spec_tile(16);
+        const uint32_t n_tiles = cdiv(n_out, T16);
         const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
         const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
         segs.wgs_per_seg = nwg;
         if (zbt) {
             // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
-            const uint64_t done = (uint64_t)n_tiles * 128u;
+            const uint64_t done = (uint64_t)n_tiles * T16;
             if (done < zbt->d_stride)
                 for (uint32_t k = 0; k < count; k++)
                     SNOUT_HIP(hipMemset2DAsync(zbt->d + (uint64_t)k * d_seg + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));

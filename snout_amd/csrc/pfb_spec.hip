@@ -128,10 +128,21 @@ __device__ __forceinline__ void lds_barrier()
 //       (tools/fmabench.hip): 2.6 against 2.8 ms per 8e8 samples.
 //   M = 16, W = 16: waves 0-3 FIR (8 outputs per thread), 4-15 FFT + 802.15.4 discriminator (a block is spread over six tile
 //       times): one FIR and three FFT waves on every SIMD.
+//   M = 16 variants (A/B builds, tools/mf_ab16.sh): SNOUT_SP16_LAYOUT = 1: 8 FIR waves (4 outputs per thread) + 8 FFT waves, a
+//       block over four tile times; 2: 256-time tiles, 8 FIR (8 outputs) + 8 FFT waves, a block over two tile times.
 template <int M, int W> struct Layout;
-template <> struct Layout<40, 12> { static constexpr int FIR = 5, OUT = 16, FFT = 6, PERIOD = 3; };
-template <> struct Layout<40, 16> { static constexpr int FIR = 10, OUT = 8, FFT = 6, PERIOD = 3; };
-template <> struct Layout<16, 16> { static constexpr int FIR = 4, OUT = 8, FFT = 12, PERIOD = 6; };
+template <> struct Layout<40, 12> { static constexpr int T = 128, FIR = 5, OUT = 16, FFT = 6, PERIOD = 3; };
+template <> struct Layout<40, 16> { static constexpr int T = 128, FIR = 10, OUT = 8, FFT = 6, PERIOD = 3; };
+#ifndef SNOUT_SP16_LAYOUT
+#define SNOUT_SP16_LAYOUT 0
+#endif
+#if SNOUT_SP16_LAYOUT == 1
+template <> struct Layout<16, 16> { static constexpr int T = 128, FIR = 8, OUT = 4, FFT = 8, PERIOD = 4; };
+#elif SNOUT_SP16_LAYOUT == 2
+template <> struct Layout<16, 16> { static constexpr int T = 256, FIR = 8, OUT = 8, FFT = 8, PERIOD = 2; };
+#else
+template <> struct Layout<16, 16> { static constexpr int T = 128, FIR = 4, OUT = 8, FFT = 12, PERIOD = 6; };
+#endif
 }  // namespace sp
 
 // Output modes: channel IQ | BTLE hard bits into the planes (M = 40) | 802.15.4 discriminator rows + IIR sums (M = 16)
@@ -143,14 +154,16 @@ void pfb_spec(const PfbMfArgs A)
 {
     using namespace sp;
     using L_ = Layout<M, W>;
-    constexpr int kFirWaves = L_::FIR, OUT = L_::OUT, NG = 64 / OUT;    // NG groups of OUT outputs per (branch, parity) and tile
+    constexpr int T = L_::T, BPT = T / 64;                              // output times per tile, 64-time blocks per tile
+    constexpr int kFirWaves = L_::FIR, OUT = L_::OUT, NG = T / 2 / OUT; // NG groups of OUT outputs per (branch, parity) and tile
     constexpr int kFftWaves = L_::FFT, PERIOD = L_::PERIOD;
-    constexpr int T = 128, M1 = M == 40 ? 8 : 4, M2 = M == 40 ? 5 : 4, ROW = M == 40 ? 42 : 18, D = M / 2, P = 16;
+    constexpr int M1 = M == 40 ? 8 : 4, M2 = M == 40 ? 5 : 4, ROW = M == 40 ? 42 : 18, D = M / 2, P = 16;
     constexpr bool PHASE_MAJOR = M == 40;               // rows in the FFT waves' lane order (M = 40) or in time order
     constexpr int SPAN = (T - 1) * D + M * P, NEW = T * D, OV = SPAN - NEW;
     constexpr int NST = 64 * kFirWaves;                 // threads that compute the FIR and stage
     static_assert(NST == 2 * M * NG && (NEW / 2) % NST == 0 && OV / 2 <= NST, "FIR / staging thread map");
-    static_assert(2 * kFftWaves == 4 * PERIOD && (MODE != kSpBtle || M == 40) && (MODE != kSpZb || M == 16), "layout");
+    static_assert(kFftWaves == BPT * PERIOD && (M != 40 || T == 128) && (MODE != kSpBtle || M == 40) && (MODE != kSpZb || M == 16), "layout");
+    static_assert(OUT % 4 == 0 && (PERIOD == 6 || PERIOD == 4 || PERIOD == 3 || PERIOD == 2), "layout");
     constexpr bool BT = MODE == kSpBtle, ZB = MODE == kSpZb;
 
     __shared__ float2 xs[2][SPAN];
@@ -197,6 +210,9 @@ void pfb_spec(const PfbMfArgs A)
         // m = e + 2 (16 grp + i) of one branch are a sliding dot product over z[q] = x[r + e D + q M]
         // =====================================================================================
         using Raw = typename IqRaw<FMT>::pair;
+#ifdef SNOUT_SP_PRIO_FIR16
+        if (M == 16) __builtin_amdgcn_s_setprio(SNOUT_SP_PRIO_FIR16);
+#endif
         const int tf = w * 64 + l, r = tf % M, e = (tf / M) & 1, grp = tf / (2 * M);
         v2f hp[P / 2];
 #pragma unroll
@@ -316,13 +332,16 @@ void pfb_spec(const PfbMfArgs A)
         // =====================================================================================
         // Wave f takes the blocks b = f + 6 k (block b = 64-time half b & 1 of tile b >> 1): tile j = f / 2 + 3 k, half
         // f & 1; a block takes three tile times: Q1 (row, first stage) | barrier | Q2 | barrier | Q3 | barrier.
-        const int f = (M == 40 && W == 12) ? (w < 8 ? w - kFirWaves : w - kFirWaves - 1) : w - kFirWaves, j0 = f >> 1, half = f & 1;
+        const int f = (M == 40 && W == 12) ? (w < 8 ? w - kFirWaves : w - kFirWaves - 1) : w - kFirWaves, j0 = f / BPT, half = f % BPT;
         // The FFT is dependency chains; the FIR waves' 256 independent packed FMAs per tile are always ready and, being the
         // older waves, would win every arbitration: FFT waves issue first (priority, then age), the FIR fills their gaps.
 #ifndef SNOUT_SP_PRIO_FFT
 #define SNOUT_SP_PRIO_FFT 2
 #endif
-        __builtin_amdgcn_s_setprio(SNOUT_SP_PRIO_FFT);
+#ifndef SNOUT_SP_PRIO_FFT16
+#define SNOUT_SP_PRIO_FFT16 SNOUT_SP_PRIO_FFT
+#endif
+        __builtin_amdgcn_s_setprio(M == 16 ? SNOUT_SP_PRIO_FFT16 : SNOUT_SP_PRIO_FFT);
         const float* const tw = M == 40 ? kTw40 : kTw16;
         const float c5_1 = kTw5[2], c5_2 = kTw5[4], s5_1 = -kTw5[3], s5_2 = -kTw5[5];
         // output time of this lane within its block
@@ -472,17 +491,20 @@ void pfb_spec(const PfbMfArgs A)
             //   discriminator values each: d[m] = fast_atan2f(y[m] conj y[m-1]) (zb_discrim.h), y[m-1] from the lane below
             //   (whole-wave DPP shift; lane 0: the block before) | Q6 the IIR sub-block sums S_j of the block's 64 values
             //   per channel, in the oracle's order (four partial sums of 16 sequential terms, S = (P0 + P1) + (P2 + P3)).
+            // (Other layouts: BPT blocks per tile, wave f <-> tile f / BPT + PERIOD k, part f % BPT; with fewer tile times per
+            // block the quarters share them: PERIOD 4 = Q1 | Q2 Q3 | Q4 Q5 | Q6, PERIOD 2 = Q1 | Q2 .. Q6.)
             float* const dl = &dls[ZB ? f : 0][0];
+            const int part = f % BPT;
             int kblk = 0;
-            for (int j = j0; j < NTL; j += PERIOD, kblk++) {
+            for (int j = f / BPT; j < NTL; j += PERIOD, kblk++) {
                 const uint32_t tile = t_lo + (uint32_t)j;
-                const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)half;
+                const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)part;
                 const bool emit = tile >= t_begin;                   // the tile before the range only supplies y[m0 - 1]
                 const uint64_t mg = m0b + mloc;
                 // ---- Q1: the row and the FFT; y_k[m] = (-1)^{km} X[k]
                 cf y[M];
                 {
-                    const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
+                    const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * part + l) * ROW]);
                     cf u[M];
 #pragma unroll
                     for (int q = 0; q < M / 2; q++) {
@@ -528,7 +550,7 @@ void pfb_spec(const PfbMfArgs A)
                 if constexpr (ZB) {
                     // y[m0 - 1]: of the block before this one (the wave before; wave 11's previous block for wave 0), zero
                     // in front of the very first block
-                    const bool have_prev = j > 0 || half == 1;
+                    const bool have_prev = j > 0 || part > 0;
                     const float2* yp = &ylast[f == 0 ? kFftWaves - 1 : f - 1][0];
                     const uint32_t left = n_out > m0b ? (uint32_t)(n_out - m0b < 64u ? n_out - m0b : 64u) : 0u;   // outputs of this block that exist
 #pragma unroll
@@ -545,19 +567,19 @@ void pfb_spec(const PfbMfArgs A)
                             if (emit) A.zb.d[(uint64_t)seg * A.segs.d_seg + (uint64_t)k * A.zb.d_stride + mg] = v;
                             dl[k * 65 + l] = v;
                         }
-                        bar();
+                        if (PERIOD == 6 || (PERIOD == 4 && (q & 1))) bar();
                     }
-                    // S_j of this block's sub-block of every channel: lane <-> (channel l / 4, part l & 3)
+                    // S_j of this block's sub-block of every channel: lane <-> (channel l / 4, quarter l & 3)
                     {
-                        const int part = l & 3, kk = l >> 2;
+                        const int qu = l & 3, kk = l >> 2;
                         double acc = 0.0;
 #pragma unroll
                         for (int i = 0; i < 16; i++)
-                            acc = acc + wts_s[63 - (16 * part + i)] * (double)dl[kk * 65 + 16 * part + i];
+                            acc = acc + wts_s[63 - (16 * qu + i)] * (double)dl[kk * 65 + 16 * qu + i];
                         acc = acc + __shfl_down(acc, 1);
                         acc = acc + __shfl_down(acc, 2);
                         const uint64_t jsb = m0b >> 6;
-                        if (emit && part == 0 && jsb < A.zb.nsb) A.zb.S[(uint64_t)seg * A.segs.S_seg + (uint64_t)kk * A.zb.nsb + jsb] = acc;
+                        if (emit && qu == 0 && jsb < A.zb.nsb) A.zb.S[(uint64_t)seg * A.segs.S_seg + (uint64_t)kk * A.zb.nsb + jsb] = acc;
                     }
                     bar();
                 } else {
@@ -589,6 +611,8 @@ extern "C" int snout_debug_sp_stamps(unsigned long long* out, uint32_t n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_stamps), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
 #endif
+
+uint32_t pfb_spec_tile(uint32_t M) { return M == 40 ? (uint32_t)sp::Layout<40, 16>::T : (uint32_t)sp::Layout<16, 16>::T; }
 
 int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
 {
