@@ -165,6 +165,15 @@ void pfb_spec(const PfbMfArgs A)
     static_assert(kFftWaves == BPT * PERIOD && (M != 40 || T == 128) && (MODE != kSpBtle || M == 40) && (MODE != kSpZb || M == 16), "layout");
     static_assert(OUT % 4 == 0 && (PERIOD == 6 || PERIOD == 4 || PERIOD == 3 || PERIOD == 2), "layout");
     constexpr bool BT = MODE == kSpBtle, ZB = MODE == kSpZb;
+    // A/B switch, measured and left OFF (profiles/r3_spec_dma_ab.txt): cf32 input global -> LDS by LDS-DMA
+    // (global_load_lds_dwordx4: no registers, no ds_write), the whole span of tile i + 1 issued at the start of tile time i
+    // (its overlap with tile i out of L2 again instead of an LDS -> LDS copy), by the FFT waves (1) or the FIR waves (2).
+    // With two xs buffers the DMA can only run ONE tile ahead and has to land before the next barrier; the register path
+    // prefetches two tiles ahead and is 2-12 % faster.  The integer formats need the conversion and use registers anyway.
+#ifndef SNOUT_SP_DMA
+#define SNOUT_SP_DMA 0
+#endif
+    constexpr bool DMA = SNOUT_SP_DMA != 0 && FMT == kFmtCf32;
 
     __shared__ float2 xs[2][SPAN];
     __shared__ float2 us[2][T * ROW];
@@ -204,6 +213,41 @@ void pfb_spec(const PfbMfArgs A)
     const unsigned long long st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    // LDS-DMA of tile nt's span into xs[nt & 1]: 1 KiB pieces (64 lanes x 16 B, LDS destination = piece base + 16 lane),
+    // piece p by wave p mod CNT of the issuing role.  A span that reaches past the segment's end is staged through registers
+    // instead (zeros past n).  Ordered for the FIR waves' reads by this wave's vmcnt(0) before the next barrier.
+    auto dma_tile = [&](int nt, int idx, auto cntc) {
+        constexpr int CNT = decltype(cntc)::value;
+        constexpr int NQ = SPAN / 2, NP = (NQ + 63) / 64;          // float4 = sample pairs of the span, pieces
+        const uint64_t base = (uint64_t)(t_lo + (uint32_t)nt) * NEW;
+        const bool full = base + SPAN <= n;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)&xs[nt & 1][0];
+#pragma unroll
+        for (int p0 = 0; p0 < NP; p0 += CNT) {
+            const int p = __builtin_amdgcn_readfirstlane(p0 + idx);
+            if (p < NP) {
+                const int q = 64 * p + l;
+                if (full) {
+                    // address = wave-uniform base (SGPR pair) + 16 lane; LDS destination = M0 + 16 lane
+                    const uint64_t gb = (uint64_t)(uintptr_t)x + (base + 128ull * (uint64_t)p) * 8ull;
+                    const uint64_t gbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb) |
+                                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb >> 32)) << 32);
+                    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)p * 1024u));
+                    if (q < NQ) {
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(16 * l), "s"(gbase), "s"(dst) : "memory");
+                    }
+                } else if (q < NQ) {
+                    const uint64_t g = base + 2ull * (uint64_t)q;
+                    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (g + 1 < n) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(x) + g);
+                    else if (g < n) { const float2 a = reinterpret_cast<const float2*>(x)[g]; v.x = a.x; v.y = a.y; }
+                    reinterpret_cast<float4*>(&xs[nt & 1][0])[q] = v;
+                }
+            }
+        }
+    };
     if (w < kFirWaves) {
         // =====================================================================================
         // FIR + staging waves: thread <-> (branch r, output parity e, group grp): the 16 outputs
@@ -299,7 +343,7 @@ void pfb_spec(const PfbMfArgs A)
             float4* xb = reinterpret_cast<float4*>(&xs[0][0]);
             const uint64_t in0 = (uint64_t)t_lo * NEW;
             for (uint32_t q = (uint32_t)tf; q < (uint32_t)(SPAN / 2); q += NST) xb[q] = iq_pair_cvt<FMT>(load_pair(in0 + 2ull * q));
-            if (1 < NTL) fetch(pre[1], t_lo + 1u);
+            if (!DMA && 1 < NTL) fetch(pre[1], t_lo + 1u);
         }
         lds_barrier();
         for (int it = 0; it < IT; it += 2) {
@@ -307,17 +351,19 @@ void pfb_spec(const PfbMfArgs A)
             for (int hb = 0; hb < 2; hb++) {
                 const int i2 = it + hb;
                 if (i2 < IT) {
+                    if constexpr (DMA && SNOUT_SP_DMA == 2) { if (i2 + 1 < NTL) dma_tile(i2 + 1, w, std::integral_constant<int, kFirWaves>{}); }
                     if (i2 < NTL) {
                         // tile i2 + 2's samples: two tiles ahead into the set tile i2's came from; tile i2 + 1's (requested
                         // one tile ago) go to LDS behind this tile's FIR: a load has one tile time + the FIR to arrive
-                        if (i2 + 2 < NTL) fetch(pre[hb], t_lo + (uint32_t)i2 + 2u);
+                        if (!DMA && i2 + 2 < NTL) fetch(pre[hb], t_lo + (uint32_t)i2 + 2u);
                         SP_STAMP(0);
                         if (hb == 0) fir_tile(std::integral_constant<int, 0>{});
                         else         fir_tile(std::integral_constant<int, 1>{});
                         SP_STAMP(1);
-                        if (i2 + 1 < NTL) stage(pre[hb ^ 1], hb ^ 1);
+                        if (!DMA && i2 + 1 < NTL) stage(pre[hb ^ 1], hb ^ 1);
                         SP_STAMP(4);
                     }
+                    if constexpr (DMA && SNOUT_SP_DMA == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lds_barrier();
                     SP_STAMP(2);
                 }
@@ -347,11 +393,14 @@ void pfb_spec(const PfbMfArgs A)
         // output time of this lane within its block
         const uint32_t mloc = PHASE_MAJOR ? 4u * (uint32_t)(l & 15) + (uint32_t)(l >> 4) : (uint32_t)l;
         int itc = 0;
-#ifdef SNOUT_MF_STAMPS
-        auto bar = [&]() { SP_STAMP(3); lds_barrier(); itc++; SP_STAMP(2); };
-#else
-        auto bar = [&]() { lds_barrier(); itc++; };
-#endif
+        auto bar = [&]() {
+            SP_STAMP(3);
+            if constexpr (DMA && SNOUT_SP_DMA == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            itc++;
+            if constexpr (DMA && SNOUT_SP_DMA == 1) { if (itc < NTL) dma_tile(itc, f, std::integral_constant<int, kFftWaves>{}); }       // tile time itc - 1 begins: tile itc's samples
+            SP_STAMP(2);
+        };
         bar();                                                       // the FIR waves' prologue
         for (int i = 0; i <= j0; i++) bar();                         // barrier j + 2 ends tile j's FIR
 
