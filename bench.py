@@ -12,12 +12,14 @@
         this one GPU, measured in the same process under the same contract.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-        cfg #5 (configs[4]): the BTLE 40-channel and the 802.15.4 16-channel wideband scans run
-        concurrently; each capture is cut into segments of 2^24 input samples that overlap by the
-        longest packet, segment i -> rank i mod N, every rank pumps its segments through its GPU,
-        the decoded records are gathered to rank 0 over RCCL and de-duplicated there, all inside the
-        timed region.  Weak scaling: every rank holds 10 s of both bands (its share of an N x 10 s
-        capture), so per-GPU work is fixed.
+        the SAME workload on every rank (weak scaling: rank r holds its own 8e8-sample capture segment, the
+        r-th 10 s of an N x 10 s capture; segments are independent, no sample ever crosses ranks), the decoded
+        records of every step gathered to rank 0 by one RCCL all_gather, overlapped with the next step, all inside
+        the timed region: value(N) / (N value(1)) is the scaling efficiency.  `other_workloads.cfg5` carries
+        BASELINE.json configs[4] on the same N ranks: the BTLE 40-channel and the 802.15.4 16-channel wideband
+        scans concurrently, each capture cut into segments of 2^24 input samples that overlap by the longest
+        packet, segment i -> rank i mod N, records gathered per step over RCCL and de-duplicated on rank 0's GPU
+        (`--workload cfg5` makes it the headline).
 
 `--workload X` runs one workload alone (N = 1: that workload is the headline; N > 1: every rank
 processes its own copy of it, records gathered per step).
@@ -505,6 +507,10 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     return res
 
 
+CFG5_FIELDS = ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu", "records_on_rank0", "decoded_crc_ok",
+               "min_expected_crc_ok", "frac", "value_per_gpu", "collective", "ranks_in_collective", "achieved_GBps", "sharding")
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -512,7 +518,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["cfg5"], default=None,
-                    help="run this workload alone (default: cfg3 + the others at N = 1, cfg5 at N > 1)")
+                    help="run this workload alone (default: cfg3 at every N, the others in other_workloads: all at N = 1, cfg5 at N > 1)")
     ap.add_argument("--samples", type=float, default=0,
                     help="complex input samples per GPU per step (default: the workload's BASELINE size)")
     ap.add_argument("--seconds", type=float, default=10.0, help="cfg5: seconds of each band per GPU")
@@ -560,7 +566,11 @@ def main():
 
     from snout_amd import dist as sdist
     fmt = {"cf32": 0, "sc8": 1, "sc16": 2}[args.format]
-    headline = args.workload or ("cfg3" if world == 1 else "cfg5")
+    # The same workload at every N (weak scaling: every rank its own capture segment of the BASELINE size, the decoded
+    # records gathered to rank 0 over RCCL inside the timed region), so that value(N) / (N value(1)) is a scaling
+    # efficiency.  BASELINE.json configs[4] (both scans in 2^24-sample segments dealt over the ranks) rides along as
+    # other_workloads.cfg5 at every N and is the headline with --workload cfg5.
+    headline = args.workload or "cfg3"
     out = None
 
     if headline == "cfg5":
@@ -626,11 +636,14 @@ def main():
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
             r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, 0, 1, seconds=args.seconds)
-            others["cfg5"] = {f: r5[f] for f in ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu",
-                                                 "records_on_rank0", "decoded_crc_ok", "min_expected_crc_ok", "frac", "value_per_gpu", "collective", "ranks_in_collective",
-                                                 "achieved_GBps", "sharding")}
-            others["cfg5"]["note"] = "what `--gpus N` measures; this is its N = 1 point"
+            others["cfg5"] = {f: r5[f] for f in CFG5_FIELDS}
+            others["cfg5"]["note"] = "BASELINE.json configs[4] on one GPU; `--gpus N` carries its N-rank point the same way"
             out["other_workloads"] = others
+        elif world > 1 and args.workload is None and not args.no_others:
+            # configs[4] on the N ranks: segments round-robin, per-step RCCL all_gather of the records, dedup on rank 0
+            r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, rank, world, seconds=args.seconds)
+            if rank == 0:
+                out["other_workloads"] = {"cfg5": {f: r5[f] for f in CFG5_FIELDS}}
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():

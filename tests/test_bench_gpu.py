@@ -70,13 +70,13 @@ def test_default_run_carries_every_workload():
 
 
 def test_two_ranks_run_cfg5_over_gloo():
-    """`--gpus N` = BASELINE.json configs[4]: both wideband scans, segments round-robin over the ranks,
+    """`--gpus N --workload cfg5` = BASELINE.json configs[4]: both wideband scans, segments round-robin over the ranks,
     records gathered and de-duplicated on rank 0 inside the timed region."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SNOUT_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg5", "--steps", "2", "--warmup", "1",
                         "--seconds", "1"], capture_output=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = _last_json(r.stdout)
@@ -89,6 +89,26 @@ def test_two_ranks_run_cfg5_over_gloo():
     # overlaps between ranks are dropped on rank 0): per GPU the two-rank run decodes as many
     one = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1")
     assert abs(c["decoded_crc_ok"] - 2 * one["config"]["decoded_crc_ok"]) <= 0.02 * c["decoded_crc_ok"]
+
+
+def test_two_ranks_default_line_is_the_headline_workload_on_every_rank():
+    """`--gpus N` without a workload: cfg #3 on every rank (the N = 1 workload, so the driver's value(N) / (N value(1))
+    is a scaling efficiency), per-step record gather to rank 0, and configs[4] on the same ranks in other_workloads."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SNOUT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--samples", "4e7", "--seconds", "1"], capture_output=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["metric"] == METRIC and d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    c = d["config"]
+    assert c["workload"].startswith("cfg3") and c["samples_per_gpu"] == 40000000 and "gather" in c["sharding"]
+    assert c["decoded_crc_ok_per_gpu"] >= c["min_expected_crc_ok_per_gpu"] > 0
+    assert d["roofline"]["kernel"] == "pfb_spec40" and 0 < d["roofline"]["frac"] < 1
+    o5 = d["other_workloads"]["cfg5"]
+    assert o5["workload"].startswith("cfg5") and o5["decoded_crc_ok"] >= o5["min_expected_crc_ok"] > 0 and o5["value"] > 0
 
 
 def test_two_ranks_single_workload_over_gloo():
