@@ -256,12 +256,20 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         torch.cuda.empty_cache()
     rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt)
 
+    gathered = [0, 0]                   # exchanges finished on rank 0, records in the last one
+
+    def take_exchange():
+        parts = gather.finish(views=True)
+        if parts is not None:
+            gathered[0] += 1
+            gathered[1] = int(sum(len(v) for v in parts))
+
     def finish_one():
         pk = rx.collect(copy=False)
         if gather is not None:
             # RCCL gather of this step's records to rank 0, overlapped with the next step
             if len(gather.inflight) == 2:
-                gather.finish(views=True)
+                take_exchange()
             gather.start(pk, rx.last_records_device()[0])      # packed from the device copy: no upload
         return pk
 
@@ -290,7 +298,7 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
 
     def drain():
         while gather is not None and gather.inflight:
-            gather.finish(views=True)
+            take_exchange()
 
     # prime the pipeline: first-use allocations of the result slots and the HIP runtime's own
     # lazily grown pools (two ~7 ms stalls were measured around the 11th and 16th submit of a process)
@@ -339,6 +347,14 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         fl = PFB_FLOP[n_ch] * n
         res["fp32"] = {"flop_per_sample": float(PFB_FLOP[n_ch]), "achieved_TFLOPs": fl / (k_avg * 1e-3) / 1e12,
                        "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": fl / (k_avg * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+    if gather is not None:
+        # the last timed step's exchange as rank 0 received it: every rank's records of that step
+        res["collective"] = "RCCL all_gather_into_tensor" if gather.backend == "nccl" else (
+            "%s all_gather_into_tensor" % gather.backend if gather.collective else "none (device copy)")
+        res["ranks_in_collective"] = gather.world
+        res["records_on_rank0_last_step"] = gathered[1]
+        if rank == 0:
+            assert gathered[1] >= len(local) * (1 if world == 1 else 0), "rank 0 received fewer records than it decoded itself"
     rx.close()
     if parity_samples:
         res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt)
@@ -588,7 +604,8 @@ def main():
                                         "launch-bound, see the single-segment kernels' fractions at N = 1"}}
     else:
         n = int(args.samples or WORKLOADS[headline][3])
-        gather = sdist.AsyncRecordGather(device, width=WORKLOADS[headline][4]) if world > 1 else None
+        # N > 1: the per-step record gather; SNOUT_BENCH_NCCL1=1 on a one-GPU box runs the same exchange on RCCL at world 1
+        gather = sdist.AsyncRecordGather(device, width=WORKLOADS[headline][4]) if (world > 1 or dist.is_initialized()) else None
         res, x = run_workload(headline, n, args.steps, args.warmup, device, rank, world, fmt=fmt, sync=args.sync,
                               gather=gather, keep_capture=True)
         if rank == 0:
@@ -610,8 +627,10 @@ def main():
                    "data": "synthetic",
                    "config": {"workload": res["workload"], "samples_per_gpu": n, "packets_per_gpu": res["packets_per_gpu"],
                               "decoded_pkts_per_s": res["decoded_pkts_per_s"],
-                              "sharding": ("every rank its own segment, per-step RCCL gather of %d-B records"
-                                           % WORKLOADS[headline][4]) if world > 1 else "single segment",
+                              "sharding": ("every rank its own segment, per-step %s gather of %d-B records to rank 0"
+                                           % (dist.get_backend(), WORKLOADS[headline][4])) if gather is not None else "single segment",
+                              **({k: res[k] for k in ("collective", "ranks_in_collective", "records_on_rank0_last_step")}
+                                 if gather is not None else {}),
                               "decoded_crc_ok_per_gpu": res["decoded_crc_ok_per_gpu"],
                               "min_expected_crc_ok_per_gpu": res["min_expected_crc_ok_per_gpu"],
                               "stepping": "one segment at a time" if args.sync else

@@ -105,6 +105,7 @@ def test_two_ranks_default_line_is_the_headline_workload_on_every_rank():
     assert KEYS <= set(d) and d["metric"] == METRIC and d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     c = d["config"]
     assert c["workload"].startswith("cfg3") and c["samples_per_gpu"] == 40000000 and "gather" in c["sharding"]
+    assert c["ranks_in_collective"] == 2 and c["records_on_rank0_last_step"] >= 1.8 * c["decoded_crc_ok_per_gpu"]
     assert c["decoded_crc_ok_per_gpu"] >= c["min_expected_crc_ok_per_gpu"] > 0
     assert d["roofline"]["kernel"] == "pfb_spec40" and 0 < d["roofline"]["frac"] < 1
     o5 = d["other_workloads"]["cfg5"]
@@ -160,3 +161,14 @@ def test_cfg5_exchange_runs_on_rccl_at_world_one():
     plain = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1")
     assert plain["config"]["collective"].startswith("none") and plain["config"]["decoded_crc_ok"] == c["decoded_crc_ok"]
     assert plain["config"]["records_on_rank0"] == c["records_on_rank0"]
+
+
+def test_headline_exchange_runs_on_rccl_at_world_one():
+    """What `--gpus N` times at N > 1 — cfg #3 with the per-step gather of the records — on a real RCCL collective at
+    world size 1 (SNOUT_BENCH_NCCL1=1): rank 0 receives exactly the records it decoded."""
+    env = dict(os.environ, SNOUT_BENCH_NCCL1="1")
+    d = _bench("--workload", "cfg3", "--steps", "3", "--warmup", "1", "--samples", "4e7", "--no-cpu", env=env)
+    c = d["config"]
+    assert c["collective"] == "RCCL all_gather_into_tensor" and c["ranks_in_collective"] == 1 and "nccl" in c["sharding"]
+    assert c["records_on_rank0_last_step"] == c["packets_per_gpu"] > 0
+    assert c["decoded_crc_ok_per_gpu"] >= c["min_expected_crc_ok_per_gpu"] > 0
