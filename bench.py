@@ -270,7 +270,9 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
             # RCCL gather of this step's records to rank 0, overlapped with the next step
             if len(gather.inflight) == 2:
                 take_exchange()
-            gather.start(pk, rx.last_records_device()[0])      # packed from the device copy: no upload
+            gather.begin(int(pk.size))
+            gather.append(pk, rx=rx)                            # packed from the device copy by one kernel: no upload
+            gather.launch()
         return pk
 
     def run_steps(k):
@@ -663,11 +665,15 @@ def main():
             r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, rank, world, seconds=args.seconds)
             if rank == 0:
                 out["other_workloads"] = {"cfg5": {f: r5[f] for f in CFG5_FIELDS}}
-    if rank == 0:
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, after the JSON:
+        # the JSON is the last line on stdout
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -232,8 +232,9 @@ class AsyncRecordGather:
             n_host = torch.zeros(1, dtype=torch.int64, pin_memory=pin)
         ev = torch.cuda.Event() if self.on_gpu else None
         up = torch.cuda.Event() if self.on_gpu else None
-        wide = torch.zeros(self.world, dtype=torch.int64, pin_memory=pin)
-        return dict(cap=cap, send=send, recv=recv, hdr=hdr, whdr=wide, host=host, n_host=n_host, ev=ev, up=up,
+        hdr2 = torch.zeros((self.world, 2), dtype=torch.int64, pin_memory=pin)      # every rank's (count, longest record)
+        hsend = torch.zeros(W, dtype=torch.uint8, pin_memory=pin)                    # this rank's header slot, staged
+        return dict(cap=cap, send=send, recv=recv, hdr=hdr, hdr2=hdr2, hsend=hsend, host=host, n_host=n_host, ev=ev, up=up,
                     fill=0, n=0, rest=[], wide=0)
 
     def _agree(self, n: int) -> int:
@@ -314,10 +315,10 @@ class AsyncRecordGather:
         self.cur = None
         W, cap = self.width, slot["cap"]
         with self._ctx():
-            hdr = np.zeros(W, dtype=np.uint8)
-            hdr[:8] = np.frombuffer(np.uint64(slot["n"]).tobytes(), dtype=np.uint8)
-            hdr[8:16] = np.frombuffer(np.uint64(slot["wide"]).tobytes(), dtype=np.uint8)      # longest record appended
-            slot["send"][:W].copy_(torch.from_numpy(hdr), non_blocking=True)
+            # header slot: true count and longest record appended.  Staged in pinned memory (an asynchronous copy); the
+            # slot is reused two launches later, after finish() has waited for this exchange's event.
+            slot["hsend"][:16].view(torch.int64).copy_(torch.tensor([slot["n"], slot["wide"]], dtype=torch.int64))
+            slot["send"][:W].copy_(slot["hsend"], non_blocking=True)
             if self.on_gpu:
                 slot["up"].record(self.stream)       # the callers' record buffers may be reused after this
             if self.collective:
@@ -325,9 +326,9 @@ class AsyncRecordGather:
             else:
                 slot["recv"].copy_(slot["send"])
             blocks = slot["recv"].view(self.world, (cap + 1) * W)
-            counts = blocks[:, :8].contiguous().view(torch.int64).reshape(self.world)
-            slot["hdr"].copy_(counts, non_blocking=True)         # every rank learns every count
-            slot["whdr"].copy_(blocks[:, 8:16].contiguous().view(torch.int64).reshape(self.world), non_blocking=True)
+            heads = blocks[:, :16].contiguous().view(torch.int64).reshape(self.world, 2)      # one kernel, one download
+            counts = heads[:, 0]
+            slot["hdr2"].copy_(heads, non_blocking=True)         # every rank learns every count and every longest record
             if self.rank == 0:
                 if self.dedup_tol is not None:
                     rows = blocks[:, W:].reshape(self.world * cap, W).view(torch.int64)
@@ -389,8 +390,9 @@ class AsyncRecordGather:
         if self.on_gpu:
             slot["ev"].synchronize()
         W, cap = self.width, slot["cap"]
-        counts = [int(c) for c in slot["hdr"].numpy()]
-        widest = int(slot["whdr"].numpy().max())
+        h2 = slot["hdr2"].numpy()
+        counts = [int(c) for c in h2[:, 0]]
+        widest = int(h2[:, 1].max())
         if widest > W - 24:             # every rank sees the same headers: every rank raises, none is left in a collective
             raise ValueError(f"a rank appended a record of {widest} bytes: it does not fit the {W}-byte wire format")
         rest = self._exchange_rest(slot, counts) if max(counts) > cap else None
