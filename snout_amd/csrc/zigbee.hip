@@ -798,11 +798,19 @@ __global__ __launch_bounds__(256) void zb_walk(
                     const uint64_t x64 = bo ? (rd.cur << bo) | (rd.n1 >> (64u - bo)) : rd.cur;
                     const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
                     uint32_t pm = 0;                    // bit k: match after chip q + k, k = 0..30
-#pragma unroll
-                    for (uint32_t k = 0; k < 31u; k++) {
+                    // With k + 1 chips in, the zero bits above them already differ from symbol 0 in
+                    // popcount(sym0 >> (k + 1)) places = 17 17 16 15 15 14 13 13 13 12 11 10 10 | 9 9 8 ...: up to the
+                    // flowgraph's threshold (10) the first 13 tests cannot pass and are not made.
+                    auto test = [&](uint32_t k) {
                         const uint32_t reg = (uint32_t)(x64 >> (63u - k));
                         pm |= (uint32_t)((uint32_t)__popc((reg & 0x7FFFFFFEu) ^ sym0) < th) << k;
+                    };
+                    if (th > 10u) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 13u; k++) test(k);
                     }
+#pragma unroll
+                    for (uint32_t k = 13u; k < 31u; k++) test(k);
                     bool hit = false;
                     uint32_t qh = 0;
                     if (pm) {
@@ -829,7 +837,15 @@ __global__ __launch_bounds__(256) void zb_walk(
                         alive = false;                  // ran to the end of the lane (or of the stream) idle
                     }
                 }
-            } else {
+            }
+#ifndef SNOUT_ZB_WALK_SPLIT
+            // A lane that has just found a first preamble symbol checks the next symbol in the SAME iteration: a wave
+            // executes both parts every iteration anyway (some lane is always in the other state), so a refuted match --
+            // nearly all of them, on noise -- costs its lane one iteration instead of two.
+            if (alive && !(s.state == 0 && s.preamble_cnt == 0)) {
+#else
+            else {
+#endif
                 // inside a (candidate) frame, one symbol: jump to the next symbol boundary
                 const uint32_t qb = q + 31u;            // q is the first chip of the symbol
                 if (qb >= total) {

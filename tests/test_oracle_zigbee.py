@@ -31,6 +31,16 @@ def test_rx_chip_words_derive_from_tx_chips(oracle):
     assert min(d[i][j] for i in range(16) for j in range(16) if i != j) >= 12
 
 
+def test_partially_filled_register_cannot_match_early(oracle):
+    """The sink's search test on a register cleared k + 1 chips ago sees zeros above them; those zeros alone differ from
+    symbol 0 in popcount(sym0 >> (k + 1)) places.  zb_walk (zigbee.hip) skips the first 13 tests for thresholds <= 10
+    on exactly this bound, and the product's table is the oracle's."""
+    sym0 = int(oracle.zb_chip_map()[0]) & 0x7FFFFFFE
+    assert sym0 == 1618456172 & 0x7FFFFFFE
+    floor = [bin(sym0 >> (k + 1)).count("1") for k in range(31)]
+    assert all(f >= 10 for f in floor[:13]) and floor[13] < 10 and floor == sorted(floor, reverse=True)
+
+
 def test_crc16_known_answer(oracle):
     assert oracle.crc16_154(b"123456789") == 0x2189          # CRC-16/KERMIT check value
     assert synth.crc16_154(b"123456789") == 0x2189
