@@ -1,4 +1,4 @@
-// pfb_spec.hip — the M = 40 channelizer as ONE workgroup of specialised waves per CU (gfx950).
+// pfb_spec.hip — the channelizer (M = 40 and M = 16) as ONE workgroup of specialised waves per CU (gfx950).
 //
 // Same arithmetic contract as pfb.hip / oracle/oracle_pfb.c (the channelizer replaces the one-channel hop of
 // snout/core/radio.py:415, snout/util/btle.py:62: SURVEY.md §8d cfg #3), other division of labour, decided by
@@ -11,20 +11,21 @@
 //     trip inside the FFT, and five-wave workgroups that put two waves on one SIMD: ~49 % of the vector issue
 //     slots are used.  Here the FIR of tile i runs BESIDE the FFTs of tiles i-1 .. i-3 on other waves:
 //
-//   waves 0-4   FIR + staging: thread <-> (branch, output parity, group of 16 outputs) as in pfb.hip, 128 output
-//               times per tile, FIR outputs double-buffered in LDS; the same threads fetch the input two tiles
-//               ahead (two register sets) and stage it behind their FIR.
-//   waves 5-7, 9-11   FFT: a thread owns one output time of a 64-time block: 20 ds_read_b128 of its row, then
-//               the whole 8 x 5 FFT of oracle_pfb.c in registers (680 VALU, no LDS round trip, no barrier
-//               inside) and the epilogue on its 40 results; a block is spread over three tile times (two
-//               barriers inside the straight-line code), so six blocks are always in flight.
+//   FIR + staging waves (M = 40: waves 0-9, M = 16: 0-3): thread <-> (branch, output parity, group of 8 outputs) as in
+//               pfb.hip, 128 output times per tile, FIR outputs double-buffered in LDS; the same threads fetch the input
+//               two tiles ahead (two register sets) and stage it behind their FIR.
+//   FFT waves (M = 40: waves 10-15, M = 16: 4-15): a thread owns one output time of a 64-time block: 20 ds_read_b128 of
+//               its row, then the whole 8 x 5 (4 x 4) FFT of oracle_pfb.c in registers (no LDS round trip, no barrier
+//               inside) and the epilogue on its results; a block is spread over three (six) tile times, barriers inside
+//               the straight-line code, so six (twelve) blocks are always in flight.
 //               BTLE: lane = 16 (m mod 4) + (m / 4 mod 16): y[m+4] is the next lane of the DPP row, and the 64
 //               lanes' hard bits of one channel come out of v_cmp as four 16-symbol pieces of its plane words;
 //               the last symbol of each piece needs the next block's first output times: those go through LDS.
-//   wave 8      idle (it only keeps the barriers' count).  Waves w, w + 4, w + 8 share a SIMD (cyclic placement),
-//               so SIMD 0 holds FIR waves 0 and 4, and the three SIMDs with ONE FIR wave hold two FFT waves
-//               each: 2 x 1024 against 1024 + 2 x 680 issue cycles per tile.  (Placement is for balance only.)
-//   One s_barrier per tile.
+//               802.15.4: the FM discriminator of the thread's 16 channels (y[m-1] = the lane below, whole-wave DPP shift)
+//               and the IIR sub-block sums of the block.
+//   One s_barrier per tile.  Waves w, w + 4, w + 8, w + 12 share a SIMD (cyclic placement): the layouts below balance
+//   FIR and FFT waves over the four SIMDs.  (A 12-wave layout with 16 outputs per FIR thread and one idle wave is kept
+//   as an A/B partner: SNOUT_PFB_IMPL=spec12.)
 #include "common.h"
 #include "iq_fmt.h"
 #include "zb_discrim.h"
@@ -114,12 +115,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
-// Two wave layouts (W = waves per workgroup):
-//   12: waves 0-4 FIR (16 outputs per thread), 8 idle, 5-7 and 9-11 FFT   -- 3 waves per SIMD, <= 168 registers
-//   16: waves 0-9 FIR ( 8 outputs per thread), 10-15 FFT                  -- 4 waves per SIMD, <= 128 registers
-// Waves w, w + 4, w + 8, w + 12 share a SIMD: with 16 waves the SIMDs hold 3 FIR + 1 FFT, 3 + 1, 2 + 2, 2 + 2 waves =
-// 2216, 2216, 2384, 2384 issue cycles per tile (FIR wave 512, FFT wave 680), and a plain VALU stream reaches 81 % of its
-// peak at four waves per SIMD against 73 % at three (tools/fmabench.hip).
 // Wave layouts (W = waves per workgroup; waves w, w + 4, w + 8, w + 12 share a SIMD):
 //   M = 40, W = 12: waves 0-4 FIR (16 outputs per thread), 8 idle, 5-7 and 9-11 FFT   -- 3 waves per SIMD, <= 168 registers
 //   M = 40, W = 16: waves 0-9 FIR ( 8 outputs per thread), 10-15 FFT                  -- 4 waves per SIMD, <= 128 registers:
