@@ -259,13 +259,19 @@ __global__ __launch_bounds__(256) void btle_corr_planes(
         // Bit-parallel pre-filter over the 64 symbol positions of the word: the newest 16 symbols of
         // the 32-symbol window must equal the top half of the access address.  T_i has, at bit l,
         // the symbol that window bit i of position l looks at.
-        uint64_t m = ~0ull;
+        // In 32-bit words: S = {pv_lo, pv_hi, w_lo, w_hi}; T_i = S >> (33 + i) = two v_alignbit_b32 (the 64-bit shifts
+        // of the plain form cost four times as much); mismatches T_i ^ (aa_i ? ~0 : 0) are OR-ed up, one v_bitop3_b32 each.
+        const uint32_t s1 = (uint32_t)(pv[j] >> 32), s2 = (uint32_t)w[j], s3 = (uint32_t)(w[j] >> 32);
+        uint32_t mm_lo = 0, mm_hi = 0;
 #pragma unroll
         for (uint32_t i = 16; i < 32u; i++) {
-            const uint64_t t = i == 31u ? w[j] : ((pv[j] >> (33u + i)) | (w[j] << (31u - i)));
-            m &= ((aa >> i) & 1u) ? t : ~t;
+            const uint32_t t_lo = i == 31u ? s2 : __builtin_amdgcn_alignbit(s2, s1, 1u + i);
+            const uint32_t t_hi = i == 31u ? s3 : __builtin_amdgcn_alignbit(s3, s2, 1u + i);
+            const uint32_t pbit = 0u - ((aa >> i) & 1u);        // uniform: all ones where the access address has a 1
+            mm_lo = __builtin_amdgcn_bitop3_b32(mm_lo, t_lo, pbit, 0xF6);      // mm | (t ^ pbit) in one v_bitop3_b32
+            mm_hi = __builtin_amdgcn_bitop3_b32(mm_hi, t_hi, pbit, 0xF6);
         }
-        cand |= (m != 0ull ? 1u : 0u) << j;
+        cand |= ((mm_lo & mm_hi) != 0xFFFFFFFFu ? 1u : 0u) << j;
     }
     // exact test (every lane one symbol position) only for the few iterations that passed
     uint64_t rows = __ballot(cand != 0u);
