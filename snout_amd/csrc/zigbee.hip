@@ -650,15 +650,20 @@ __global__ __launch_bounds__(256) void zb_match(const unsigned long long* __rest
     const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
     const uint64_t cur = sw[wi], prev = wi ? sw[wi - 1u] : 0ull;
     const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
-    uint64_t m = 0;
+    // the window ending at chip i = the low 32 bits of {prev, cur} >> (63 - i): one v_alignbit_b32 on 32-bit words
+    // (64-bit shifts cost four times as much); (x & mask) ^ sym0 is one v_bitop3_b32
+    const uint32_t v0 = (uint32_t)cur, v1 = (uint32_t)(cur >> 32), v2 = (uint32_t)prev;
+    uint32_t m_hi = 0, m_lo = 0;            // bit 63 - i of the match word
 #pragma unroll
     for (uint32_t i = 0; i < 64u; i++) {
-        uint64_t x = cur >> (63u - i);
-        if (i < 31u) x |= prev << (i + 1u);
-        const uint32_t dist = (uint32_t)__popc(((uint32_t)x & 0x7FFFFFFEu) ^ sym0);
-        m |= (uint64_t)(dist < th) << (63u - i);
+        const uint32_t sft = 63u - i;
+        const uint32_t x = sft >= 32u ? (sft == 32u ? v1 : __builtin_amdgcn_alignbit(v2, v1, sft - 32u))
+                                      : (sft == 0u ? v0 : __builtin_amdgcn_alignbit(v1, v0, sft));
+        const uint32_t dist = (uint32_t)__popc(__builtin_amdgcn_bitop3_b32(x, 0x7FFFFFFEu, sym0, 0x6A));   // (a & b) ^ c
+        const uint32_t hit = dist < th ? 1u : 0u;
+        if (sft >= 32u) m_hi |= hit << (sft - 32u); else m_lo |= hit << sft;
     }
-    match[(uint64_t)slot * stream_words + wi] = m;
+    match[(uint64_t)slot * stream_words + wi] = ((uint64_t)m_hi << 32) | m_lo;
 }
 
 // Sequential reader of one channel's chip stream: the sink only moves forward, so the words around
