@@ -471,27 +471,26 @@ __global__ __launch_bounds__(256) void zb_offsets(const uint32_t* __restrict__ o
 }
 
 // Owned chips of every lane -> the channel's chip stream (chip q at bit 63 - q % 64 of word q / 64).
-// Thread = lane: it appends the owned part of its tile records to a 64-bit accumulator and stores
-// every completed word; only the two words it may share with its neighbours (the first if it
-// starts inside a word, and the last) are merged with atomicOr into the zeroed stream.  The
-// records of 64 consecutive lanes are coalesced lines.
-__global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ TR, uint32_t nt,
-                                                  uint32_t lanes_per_slot, uint32_t total_lanes,
-                                                  uint32_t first_tile,
-                                                  const uint32_t* __restrict__ first_owned,
-                                                  const uint32_t* __restrict__ offs,
-                                                  unsigned long long* __restrict__ stream, uint64_t stream_words)
+// Thread = lane: it appends the owned part of its tile records to a 64-bit accumulator and emits every
+// completed word.  The records of 64 consecutive lanes are coalesced lines; the words are not -- every
+// lane fills its own stretch of the stream, so 64 lanes storing at once touch 64 different lines with
+// 8 bytes each (round 2: 4.3 x the stream's bytes in HBM writes).  A wave whose lanes lie in one channel
+// therefore assembles its stretch (its lanes' stretches are adjacent: ~ core / 2 chips each) in LDS with
+// ds_or_b64 and writes it out in whole lines; only the first and the last word of the stretch, which it may
+// share with the neighbouring waves, go through atomicOr into the zeroed stream.  Waves that span two
+// channels, and lane shapes whose stretch does not fit (wcap words per wave, 0 = never), store directly.
+template <bool STAGED>
+__device__ __forceinline__ void scatter_lane(const uint32_t* __restrict__ TR, uint32_t nt, uint32_t w, uint32_t row,
+                                             uint32_t t0, uint32_t f, uint32_t o, unsigned long long* __restrict__ sw,
+                                             unsigned long long* lds, uint32_t wb)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= total_lanes) return;
-    const uint32_t w = g >> 6, row = g & 63u;
-    const uint32_t f = first_owned[g], o = offs[g];
-    unsigned long long* sw = stream + (uint64_t)(g / lanes_per_slot) * stream_words;
     uint32_t wi = o >> 6, fill = o & 63u;
     bool shared = fill != 0u;                   // the word being filled started before this lane
     uint64_t acc = 0;
-    // chips before the candidate tile are never owned (a lane without predecessor owns from chip 0)
-    const uint32_t t0 = (g % lanes_per_slot) ? first_tile : 0u;
+    auto put = [&](uint32_t widx, uint64_t v, bool sh) {
+        if constexpr (STAGED) { atomicOr(&lds[widx - wb], (unsigned long long)v); }
+        else { if (sh) atomicOr(&sw[widx], (unsigned long long)v); else sw[widx] = v; }
+    };
 #pragma unroll 4
     for (uint32_t t = t0; t < nt; t++) {
         const uint32_t nc = TR[tr_index(w, nt, t, 6, row)] & 0xFFFFu;
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ T
         const uint64_t bits = (cw << skip) & (~0ull << (64u - cnt));
         acc |= bits >> fill;
         if (fill + cnt >= 64u) {
-            if (shared) atomicOr(&sw[wi], acc); else sw[wi] = acc;
+            put(wi, acc, shared);
             shared = false;
             wi++;
             acc = fill ? bits << (64u - fill) : 0ull;
@@ -512,7 +511,48 @@ __global__ __launch_bounds__(256) void zb_scatter(const uint32_t* __restrict__ T
             fill += cnt;
         }
     }
-    if (fill != 0u && acc != 0ull) atomicOr(&sw[wi], acc);
+    if (fill != 0u && acc != 0ull) put(wi, acc, true);
+}
+
+__global__ __launch_bounds__(128) void zb_scatter(const uint32_t* __restrict__ TR, uint32_t nt,
+                                                  uint32_t lanes_per_slot, uint32_t total_lanes,
+                                                  uint32_t first_tile,
+                                                  const uint32_t* __restrict__ first_owned,
+                                                  const uint32_t* __restrict__ offs, const uint32_t* __restrict__ owned,
+                                                  unsigned long long* __restrict__ stream, uint64_t stream_words,
+                                                  uint32_t wcap)
+{
+    extern __shared__ unsigned long long scat_lds[];
+    const uint32_t g = blockIdx.x * 128u + threadIdx.x;
+    const uint32_t l = threadIdx.x & 63u;
+    const uint32_t g0 = g - l;                                   // the wave's first lane
+    if (g0 >= total_lanes) return;
+    const uint32_t g1 = (g0 + 63u < total_lanes ? g0 + 63u : total_lanes - 1u);          // ... and its last
+    const bool active = g < total_lanes;
+    const uint32_t gs = active ? g : g1;
+    const uint32_t w = gs >> 6, row = gs & 63u;
+    const uint32_t f = first_owned[gs], o = offs[gs];
+    unsigned long long* sw = stream + (uint64_t)(gs / lanes_per_slot) * stream_words;
+    // chips before the candidate tile are never owned (a lane without predecessor owns from chip 0)
+    const uint32_t t0 = (gs % lanes_per_slot) ? first_tile : 0u;
+    // the wave's stretch of the stream: words wb .. we of one channel
+    const uint32_t o0 = offs[g0], e1 = offs[g1] + owned[g1];
+    const uint32_t wb = o0 >> 6, we = e1 ? (e1 - 1u) >> 6 : 0u;
+    const bool staged = wcap != 0u && g0 / lanes_per_slot == g1 / lanes_per_slot && e1 > o0 && we - wb < wcap;
+    if (!staged) {
+        if (active) scatter_lane<false>(TR, nt, w, row, t0, f, o, sw, nullptr, 0u);
+        return;
+    }
+    unsigned long long* lds = scat_lds + (size_t)(threadIdx.x >> 6) * wcap;
+    const uint32_t nw = we - wb + 1u;
+    for (uint32_t k = l; k < nw; k += 64u) lds[k] = 0ull;
+    // (one wave's LDS instructions execute in order: no barrier between its own zeroing, OR-ing and reading)
+    if (active) scatter_lane<true>(TR, nt, w, row, t0, f, o, sw, lds, wb);
+    for (uint32_t k = l; k < nw; k += 64u) {
+        const unsigned long long v = lds[k];
+        if (k == 0u || k + 1u == nw) { if (v) atomicOr(&sw[wb + k], v); }
+        else sw[wb + k] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1241,9 +1281,15 @@ int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
                        tiles_per_slot, first_owned, owned, tsum, seam);
     hipLaunchKernelGGL(zb_offsets, dim3(tiles_per_slot, n_slots), dim3(256), 0, st, owned, tsum,
                        lanes_per_slot, tiles_per_slot, offs, slot_total);
-    hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_TR.as<uint32_t>(), nt,
-                       lanes_per_slot, total_lanes, warmup >= 64u ? (warmup >> 6) - 1u : 0u, first_owned, offs,
-                       d_stream.as<unsigned long long>(), stream_words);
+    {
+        // a wave's stretch of the stream: 64 lanes x ~ core / 2 chips (the loop's step stays within 2 (1 +- 0.0002));
+        // staged through LDS while two waves' stretches fit 48 KB, stored directly otherwise
+        const uint32_t want = core / 2u + 64u;                          // words per wave
+        const uint32_t wcap = (uint64_t)want * 16u <= 48u * 1024u ? want : 0u;
+        hipLaunchKernelGGL(zb_scatter, dim3(cdiv(total_lanes, 128)), dim3(128), (size_t)wcap * 16u, st, d_TR.as<uint32_t>(), nt,
+                           lanes_per_slot, total_lanes, warmup >= 64u ? (warmup >> 6) - 1u : 0u, first_owned, offs, owned,
+                           d_stream.as<unsigned long long>(), stream_words, wcap);
+    }
     hipLaunchKernelGGL(zb_match, dim3(cdiv(stream_words, 256), n_slots), dim3(256), 0, st,
                        d_stream.as<unsigned long long>(), stream_words, slot_total, threshold,
                        d_stream.as<unsigned long long>() + stream_words * n_slots);
