@@ -680,13 +680,19 @@ __device__ __forceinline__ bool sink_symbol(SinkState& s, uint32_t th, uint8_t* 
 // Full-register preamble matches of the whole stream, all chips in parallel: bit (63 - q % 64) of
 // match[q / 64] = popcount((window of 32 chips ending at q) ^ symbol 0, masked) < threshold, i.e. what
 // the sink's search test yields once at least 32 chips have been shifted in since it was cleared.
+// Written as PAIRS {chips, match} (16 bytes per 64 chips): zb_walk's lanes read scattered words, one lane per
+// line, and what bounds it at scale is the number of such requests -- one 16-byte load now brings both words.
 __global__ __launch_bounds__(256) void zb_match(const unsigned long long* __restrict__ stream,
                                                 uint64_t stream_words, const uint32_t* __restrict__ slot_total,
-                                                uint32_t th, unsigned long long* __restrict__ match)
+                                                uint32_t th, ulonglong2* __restrict__ pairs)
 {
     const uint32_t slot = blockIdx.y;
     const uint64_t wi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (wi >= stream_words || wi * 64u >= (uint64_t)slot_total[slot]) return;
+    if (wi >= stream_words) return;
+    if (wi * 64u >= (uint64_t)slot_total[slot]) {          // behind the channel's last chip: defined (zero) words
+        pairs[(uint64_t)slot * stream_words + wi] = make_ulonglong2(0ull, 0ull);
+        return;
+    }
     const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
     const uint64_t cur = sw[wi], prev = wi ? sw[wi - 1u] : 0ull;
     const uint32_t sym0 = kChipMap[0] & 0x7FFFFFFEu;
@@ -703,24 +709,36 @@ __global__ __launch_bounds__(256) void zb_match(const unsigned long long* __rest
         const uint32_t hit = dist < th ? 1u : 0u;
         if (sft >= 32u) m_hi |= hit << (sft - 32u); else m_lo |= hit << sft;
     }
-    match[(uint64_t)slot * stream_words + wi] = ((uint64_t)m_hi << 32) | m_lo;
+    pairs[(uint64_t)slot * stream_words + wi] = make_ulonglong2(cur, ((uint64_t)m_hi << 32) | m_lo);
 }
 
-// Sequential reader of one channel's chip stream: the sink only moves forward, so the words around
+// Sequential reader of one channel's {chips, match} pairs: the sink only moves forward, so the words around
 // the cursor stay in registers and the next two are always in flight.
 struct ChipReader {
-    const unsigned long long* sw;
+    const ulonglong2* sw;
     uint32_t wi;                    // index of `cur`
-    uint64_t prev, cur, n1, n2;
-    __device__ __forceinline__ void open(const unsigned long long* s, uint32_t q)
+    uint64_t prev, cur, n1, n2;     // chips of words wi - 1 .. wi + 2
+    uint64_t mcur, mn1, mn2;        // match masks of words wi .. wi + 2
+    __device__ __forceinline__ void open(const ulonglong2* s, uint32_t q)
     {
         sw = s; wi = q >> 6;
-        prev = wi ? sw[wi - 1u] : 0ull; cur = sw[wi]; n1 = sw[wi + 1u]; n2 = sw[wi + 2u];
+        const ulonglong2 a = sw[wi], b = sw[wi + 1u], c = sw[wi + 2u];
+        prev = wi ? sw[wi - 1u].x : 0ull;
+        cur = a.x; mcur = a.y; n1 = b.x; mn1 = b.y; n2 = c.x; mn2 = c.y;
     }
     __device__ __forceinline__ void seek(uint32_t q)        // q >= 64 * wi
     {
         if ((q >> 6) > wi + 2u) { open(sw, q); return; }     // far jump: four independent loads
-        while (wi < (q >> 6)) { prev = cur; cur = n1; n1 = n2; wi++; n2 = sw[wi + 2u]; }
+        while (wi < (q >> 6)) {
+            prev = cur; cur = n1; n1 = n2; mcur = mn1; mn1 = mn2; wi++;
+            const ulonglong2 c = sw[wi + 2u];
+            n2 = c.x; mn2 = c.y;
+        }
+    }
+    // match mask of word wq >= wi: from the registers when it is one of the three held, else one load
+    __device__ __forceinline__ uint64_t match_word(uint32_t wq) const
+    {
+        return wq == wi ? mcur : (wq == wi + 1u ? mn1 : (wq == wi + 2u ? mn2 : sw[wq].y));
     }
     __device__ __forceinline__ uint32_t bit(uint32_t q) const { return (uint32_t)(cur >> (63u - (q & 63u))) & 1u; }
     // the 32 chips ending at chip q (chip q in bit 0); q >= 31, in the current word
@@ -734,7 +752,7 @@ struct ChipReader {
 };
 
 __global__ __launch_bounds__(256) void zb_walk(
-    const unsigned long long* __restrict__ stream, const unsigned long long* __restrict__ match,
+    const ulonglong2* __restrict__ pairs,
     uint64_t stream_words, const uint32_t* __restrict__ offs,
     const uint32_t* __restrict__ first_owned, const uint32_t* __restrict__ slot_total,
     const uint32_t* __restrict__ TR, uint32_t nt, uint32_t lanes_per_slot, uint32_t total_lanes,
@@ -749,8 +767,7 @@ __global__ __launch_bounds__(256) void zb_walk(
     const uint32_t gs = exists ? g : 0u;
     const uint32_t slot = gs / lanes_per_slot, li = gs % lanes_per_slot;
     const uint64_t first_index = segs.first[slot / segs.slots_per_seg];     // the slot's segment of a batch
-    const unsigned long long* sw = stream + (uint64_t)slot * stream_words;
-    const unsigned long long* mt = match + (uint64_t)slot * stream_words;
+    const ulonglong2* sw = pairs + (uint64_t)slot * stream_words;
     const uint32_t total = exists ? slot_total[slot] : 0u;
     const uint32_t own0 = offs[gs];
     const uint32_t own1 = li + 1u < lanes_per_slot ? offs[gs + 1u] : total;
@@ -763,8 +780,6 @@ __global__ __launch_bounds__(256) void zb_walk(
     ChipReader rd;
     rd.open(sw, q);
     bool alive = exists && q < total;
-    uint32_t pf_w = 0xFFFFFFF0u;                    // match words fetched ahead for the next search: index,
-    uint64_t pf_m0 = 0, pf_m1 = 0;                  // words pf_w and pf_w + 1
     auto bcast = [](uint32_t v, int src) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
     while (__ballot(alive) != 0ull) {
         bool fin = false, stepped = false;
@@ -783,7 +798,7 @@ __global__ __launch_bounds__(256) void zb_walk(
             need &= need - 1ull;
             const uint32_t q0 = bcast(q, src), tot0 = bcast(total, src);
             const uint32_t rem = bcast((uint32_t)(s.packetlen - s.payload_cnt), src);
-            const unsigned long long* sw0 = (const unsigned long long*)(uintptr_t)(
+            const ulonglong2* sw0 = (const ulonglong2*)(uintptr_t)(
                 (uint64_t)bcast((uint32_t)(uintptr_t)sw, src) | ((uint64_t)bcast((uint32_t)((uint64_t)(uintptr_t)sw >> 32), src) << 32));
             uint32_t S = 2u * rem < 64u ? 2u * rem : 64u;
             const uint32_t fit = (tot0 - q0) >> 5;                 // symbols whose last chip is in the stream
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(256) void zb_walk(
             if (lane < S) {
                 const uint32_t qe = q0 + 31u + 32u * lane;          // last chip of symbol `lane`
                 const uint32_t wi2 = qe >> 6, sh = 63u - (qe & 63u);
-                const uint64_t cur = sw0[wi2], prv = wi2 ? sw0[wi2 - 1u] : 0ull;
+                const uint64_t cur = sw0[wi2].x, prv = wi2 ? sw0[wi2 - 1u].x : 0ull;
                 uint64_t xw = cur >> sh;
                 if (sh > 32u) xw |= prv << (64u - sh);
                 nwv = nearest_word((uint32_t)xw);
@@ -862,12 +877,12 @@ __global__ __launch_bounds__(256) void zb_walk(
                         qh = q + (uint32_t)__ffs((int)pm) - 1u;
                         hit = qh < lim;
                     } else {
-                        // ... then the precomputed full-register matches, a word at a time; the first two
-                        // words were requested an iteration ago when this restart was foreseeable
+                        // ... then the precomputed full-register matches, a word at a time: the reader holds the
+                        // masks of the cursor's word and the two behind it beside their chips
                         uint32_t qs = q + 31u;
                         while (qs < lim) {
                             const uint32_t wq = qs >> 6;
-                            const uint64_t word = wq == pf_w ? pf_m0 : (wq == pf_w + 1u ? pf_m1 : mt[wq]);
+                            const uint64_t word = rd.match_word(wq);
                             const uint64_t mw = word & (~0ull >> (qs & 63u));
                             if (mw) { qh = (qs & ~63u) + (uint32_t)__clzll((long long)mw); hit = qh < lim; break; }
                             qs = (qs & ~63u) + 64u;
@@ -900,11 +915,6 @@ __global__ __launch_bounds__(256) void zb_walk(
                     s.shift = rd.window32(qb);
                     uint8_t* pb = (uint8_t*)(uintptr_t)pb_me;
                     const int state_before = s.state;
-                    if (state_before == 0) {            // most such checks fail: the search resumes at qb + 1
-                        pf_w = (qb + 32u) >> 6;
-                        pf_m0 = mt[pf_w];
-                        pf_m1 = mt[pf_w + 1u];
-                    }
                     fin = sink_symbol(s, th, pb);
                     if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
                     q = qb + 1u;
@@ -1240,7 +1250,7 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
     // first_owned | owned | offs | tsum | slot_total
     // first_owned | owned | offs | tsum | slot_total | (8-byte aligned) seam masks, one u64 per lane
     if (int rc = d_lane_u32.ensure(((uint64_t)total_lanes * 3u + (uint64_t)tiles_per_slot * n_slots + n_slots + 2u) * 4u + (uint64_t)total_lanes * 8u)) return rc;
-    if (int rc = d_stream.ensure(stream_words * n_slots * 8u * 2u)) return rc;     // chips | match masks
+    if (int rc = d_stream.ensure(stream_words * n_slots * 8u * 3u)) return rc;     // chips | {chips, match} pairs
     if (int rc = d_stage.ensure((uint64_t)total_lanes * pkts_per_lane * sizeof(snout_pkt))) return rc;
     if (int rc = d_lane_cnt.ensure(2u * ((uint64_t)total_lanes + 1024u) * 4u)) return rc;     // raw counts, kept counts
     max_out = total_lanes * pkts_per_lane;
@@ -1292,9 +1302,9 @@ int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
     }
     hipLaunchKernelGGL(zb_match, dim3(cdiv(stream_words, 256), n_slots), dim3(256), 0, st,
                        d_stream.as<unsigned long long>(), stream_words, slot_total, threshold,
-                       d_stream.as<unsigned long long>() + stream_words * n_slots);
+                       reinterpret_cast<ulonglong2*>(d_stream.as<unsigned long long>() + stream_words * n_slots));
     hipLaunchKernelGGL(zb_walk, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st,
-                       d_stream.as<unsigned long long>(), d_stream.as<unsigned long long>() + stream_words * n_slots,
+                       reinterpret_cast<const ulonglong2*>(d_stream.as<unsigned long long>() + stream_words * n_slots),
                        stream_words, offs, first_owned, slot_total,
                        d_TR.as<uint32_t>(), nt, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), segs, d_stage.as<snout_pkt>(), pkts_per_lane,
