@@ -751,6 +751,9 @@ struct ChipReader {
     }
 };
 
+#ifdef SNOUT_ZB_WALK_STAMPS
+__device__ unsigned long long g_walk_stamps[8192 * 4];      // diagnostic build (tools/walk_stamps.py): per wave iterations, cycles, lane-iterations searching / in a symbol
+#endif
 __global__ __launch_bounds__(256) void zb_walk(
     const ulonglong2* __restrict__ pairs,
     uint64_t stream_words, const uint32_t* __restrict__ offs,
@@ -781,7 +784,15 @@ __global__ __launch_bounds__(256) void zb_walk(
     rd.open(sw, q);
     bool alive = exists && q < total;
     auto bcast = [](uint32_t v, int src) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+#ifdef SNOUT_ZB_WALK_STAMPS
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_it = 0, st_srch = 0, st_sym = 0;
+#endif
     while (__ballot(alive) != 0ull) {
+#ifdef SNOUT_ZB_WALK_STAMPS
+        st_it++;
+        st_srch += __popcll(__ballot(alive && s.state == 0 && s.preamble_cnt == 0));
+        st_sym += __popcll(__ballot(alive && !(s.state == 0 && s.preamble_cnt == 0)));
+#endif
         bool fin = false, stepped = false;
         // ---- payload, cooperatively.  A lane inside the payload of a frame (state 2, at a byte
         //      boundary, at least two bytes to go) would otherwise take one symbol per iteration while
@@ -984,7 +995,21 @@ __global__ __launch_bounds__(256) void zb_walk(
         }
     }
     if (exists) lane_cnt[g] = n_pk;
+#ifdef SNOUT_ZB_WALK_STAMPS
+    if (lane == 0 && (g >> 6) < 8192u) {
+        g_walk_stamps[(g >> 6) * 4u + 0u] = st_it;
+        g_walk_stamps[(g >> 6) * 4u + 1u] = __builtin_amdgcn_s_memtime() - st_t0;
+        g_walk_stamps[(g >> 6) * 4u + 2u] = st_srch;
+        g_walk_stamps[(g >> 6) * 4u + 3u] = st_sym;
+    }
+#endif
 }
+#ifdef SNOUT_ZB_WALK_STAMPS
+extern "C" int snout_debug_walk_stamps(unsigned long long* out, uint32_t n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_stamps), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+}
+#endif
 
 // The sequential rule over the candidate frames of all lanes (see the oracle, "Resolve"): in the
 // order of their SFD chips (= lane order, then time), a frame is kept iff its trigger chip lies after
