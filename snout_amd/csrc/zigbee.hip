@@ -166,6 +166,10 @@ constexpr int kZRow = 41;          // per-lane z buffer: 8 samples of history + 
 // 16-B slot = row mod 16, so the 16 lanes of a read group spread over all slots
 constexpr uint32_t kMaxCand = 12;
 constexpr uint32_t kSinkWarmChips = 512;    // sink warm-up on the stitched stream (ORACLE_ZB_SINK_WARM)
+#ifndef SNOUT_ZB_COOP_GROUPS
+#define SNOUT_ZB_COOP_GROUPS 4
+#endif
+constexpr uint32_t kCoopGroups = SNOUT_ZB_COOP_GROUPS;     // frames decoded per cooperative round of zb_walk (1, 2 or 4)
 
 // What a lane hands to the stitcher (see oracle_zigbee.c "Stitching").
 struct ZbLaneOut {
@@ -783,7 +787,6 @@ __global__ __launch_bounds__(256) void zb_walk(
     ChipReader rd;
     rd.open(sw, q);
     bool alive = exists && q < total;
-    auto bcast = [](uint32_t v, int src) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
 #ifdef SNOUT_ZB_WALK_STAMPS
     unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_it = 0, st_srch = 0, st_sym = 0;
 #endif
@@ -804,55 +807,90 @@ __global__ __launch_bounds__(256) void zb_walk(
                           q + 63u < total;
         uint64_t need = __ballot(elig);
         const uint64_t pb_me = (exists && n_pk < K) ? (uint64_t)(uintptr_t)stage[(size_t)g * K + n_pk].bytes : 0ull;
+        // kCoopGroups frames per round: group gi = lane / W decodes up to W = 64 / kCoopGroups symbols of ITS source lane's
+        // frame (lane takes symbol lane % W).  A round stands on one load however many frames it serves, and a wave
+        // that receives traffic has several lanes inside payloads at once (tools/walk_stamps.py: 9 of 64 in a symbol).
+        constexpr uint32_t G = kCoopGroups, W = 64u / G;
+        const uint32_t gi = lane / W, sl = lane % W;
         while (need != 0ull) {
-            const int src = __builtin_ctzll(need);
-            need &= need - 1ull;
-            const uint32_t q0 = bcast(q, src), tot0 = bcast(total, src);
-            const uint32_t rem = bcast((uint32_t)(s.packetlen - s.payload_cnt), src);
+            int src = -1;                       // my group's source lane this round
+            int srcs[G];
+#pragma unroll
+            for (uint32_t k = 0; k < G; k++) {
+                srcs[k] = -1;
+                if (need != 0ull) { srcs[k] = __builtin_ctzll(need); need &= need - 1ull; }
+                if (k == gi) src = srcs[k];
+            }
+            const bool has = src >= 0;
+            const int from = has ? src : (int)lane;
+            const uint32_t q0 = (uint32_t)__shfl((int)q, from), tot0 = (uint32_t)__shfl((int)total, from);
+            const uint32_t rem = (uint32_t)__shfl((int)(s.packetlen - s.payload_cnt), from);
             const ulonglong2* sw0 = (const ulonglong2*)(uintptr_t)(
-                (uint64_t)bcast((uint32_t)(uintptr_t)sw, src) | ((uint64_t)bcast((uint32_t)((uint64_t)(uintptr_t)sw >> 32), src) << 32));
-            uint32_t S = 2u * rem < 64u ? 2u * rem : 64u;
+                (uint64_t)(uint32_t)__shfl((int)(uint32_t)(uintptr_t)sw, from) |
+                ((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)(uintptr_t)sw >> 32), from) << 32));
+            uint32_t S = 2u * rem < W ? 2u * rem : W;
             const uint32_t fit = (tot0 - q0) >> 5;                 // symbols whose last chip is in the stream
             S = S < fit ? S : fit;
             uint32_t nwv = 0xFF00u;                                 // distance 255: invalid
-            if (lane < S) {
-                const uint32_t qe = q0 + 31u + 32u * lane;          // last chip of symbol `lane`
+            if (has && sl < S) {
+                const uint32_t qe = q0 + 31u + 32u * sl;            // last chip of symbol `sl`
                 const uint32_t wi2 = qe >> 6, sh = 63u - (qe & 63u);
                 const uint64_t cur = sw0[wi2].x, prv = wi2 ? sw0[wi2 - 1u].x : 0ull;
                 uint64_t xw = cur >> sh;
                 if (sh > 32u) xw |= prv << (64u - sh);
                 nwv = nearest_word((uint32_t)xw);
             }
-            const uint64_t okm = __ballot(lane < S && (nwv >> 8) < th);
-            const uint32_t first_bad = ~okm ? (uint32_t)__builtin_ctzll(~okm) : 64u;
-            const uint32_t vb = (first_bad < S ? first_bad : S) >> 1;       // whole bytes in the valid prefix
-            if (vb == 0u) continue;                                  // the one-symbol path takes it from here
+            const uint64_t okm_all = __ballot(has && sl < S && (nwv >> 8) < th);
+            const uint64_t maskW = W == 64u ? ~0ull : ((1ull << (W & 63u)) - 1ull);
+            const uint64_t bad = ~(okm_all >> (W * gi)) & maskW;    // my group's symbols that failed (or lie behind S)
+            const uint32_t first_bad = bad ? (uint32_t)__builtin_ctzll(bad) : W;
+            const uint32_t vb = has ? (first_bad < S ? first_bad : S) >> 1 : 0u;       // whole bytes in the valid prefix
+            // vb == 0: the one-symbol path takes that frame from here.  Everything below is computed alike by all lanes of
+            // a group; the source lane, wherever it sits, picks its group's results up afterwards.
+            const int base = (int)(W * gi);
             // link quality: the first eight symbols of a frame
-            uint32_t lqi0 = bcast(s.lqi, src), lqc0 = bcast(s.lqi_cnt, src);
-            for (uint32_t j = 0; j < 2u * vb && lqc0 < 8u; j++) { lqi0 += 32u - (bcast(nwv, (int)j) >> 8); lqc0++; }
+            uint32_t lqi0 = (uint32_t)__shfl((int)s.lqi, from), lqc0 = (uint32_t)__shfl((int)s.lqi_cnt, from);
+#pragma unroll
+            for (uint32_t j = 0; j < (W < 8u ? W : 8u); j++) {
+                const uint32_t dj = (uint32_t)__shfl((int)nwv, base + (int)j) >> 8;
+                if (j < 2u * vb && lqc0 < 8u) { lqi0 += 32u - dj; lqc0++; }
+            }
             // bytes: low nibble first
             const uint32_t nib = nwv & 15u;
             const uint32_t byte = nib | (((uint32_t)__shfl_down((int)nib, 1)) << 4);    // even lanes
-            const uint32_t cnt0 = bcast((uint32_t)s.packetlen_cnt, src);
-            uint8_t* pb0 = (uint8_t*)(uintptr_t)((uint64_t)bcast((uint32_t)pb_me, src) |
-                                                 ((uint64_t)bcast((uint32_t)(pb_me >> 32), src) << 32));
-            if (pb0 && !(lane & 1u) && lane < 2u * vb) pb0[cnt0 + (lane >> 1)] = (uint8_t)byte;
-            // running FCS and the last two bytes: sequential over the bytes, on uniform values
-            uint32_t c0 = bcast(s.c0, src), c1 = bcast(s.c1, src), c2 = bcast(s.c2, src);
-            uint32_t bp = bcast(s.b_prev, src), bl = bcast(s.b_last, src);
-            for (uint32_t k = 0; k < vb; k++) {
-                const uint32_t bk = bcast(byte, (int)(2u * k));
-                c2 = c1; c1 = c0; c0 = crc16_step(c0, bk);
-                bp = bl; bl = bk;
+            const uint32_t cnt0 = (uint32_t)__shfl(s.packetlen_cnt, from);
+            uint8_t* pb0 = (uint8_t*)(uintptr_t)((uint64_t)(uint32_t)__shfl((int)(uint32_t)pb_me, from) |
+                                                 ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pb_me >> 32), from) << 32));
+            if (pb0 && !(sl & 1u) && sl < 2u * vb) pb0[cnt0 + (sl >> 1)] = (uint8_t)byte;
+            // running FCS and the last two bytes: sequential over the bytes
+            uint32_t c0 = (uint32_t)__shfl((int)s.c0, from), c1 = (uint32_t)__shfl((int)s.c1, from), c2 = (uint32_t)__shfl((int)s.c2, from);
+            uint32_t bp = (uint32_t)__shfl((int)s.b_prev, from), bl = (uint32_t)__shfl((int)s.b_last, from);
+#pragma unroll
+            for (uint32_t k = 0; k < W / 2u; k++) {
+                const uint32_t bk = (uint32_t)__shfl((int)byte, base + (int)(2u * k));
+                if (k < vb) {
+                    c2 = c1; c1 = c0; c0 = crc16_step(c0, bk);
+                    bp = bl; bl = bk;
+                }
             }
-            if ((int)lane == src) {
-                s.lqi = lqi0; s.lqi_cnt = lqc0;
-                s.c0 = c0; s.c1 = c1; s.c2 = c2; s.b_prev = bp; s.b_last = bl;
-                s.packetlen_cnt += (int)vb; s.payload_cnt += (int)vb;
-                s.packet_byte = (int)bl;
-                q += 64u * vb;
-                fin = s.payload_cnt >= s.packetlen;
-                stepped = true;
+            // hand the results to the source lanes
+#pragma unroll
+            for (uint32_t k = 0; k < G; k++) {
+                const int gl = (int)(W * k);                         // a lane of group k
+                const uint32_t r_vb = (uint32_t)__builtin_amdgcn_readlane((int)vb, gl);
+                const uint32_t r_lqi = (uint32_t)__builtin_amdgcn_readlane((int)lqi0, gl), r_lqc = (uint32_t)__builtin_amdgcn_readlane((int)lqc0, gl);
+                const uint32_t r_c0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, gl), r_c1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, gl);
+                const uint32_t r_c2 = (uint32_t)__builtin_amdgcn_readlane((int)c2, gl);
+                const uint32_t r_bp = (uint32_t)__builtin_amdgcn_readlane((int)bp, gl), r_bl = (uint32_t)__builtin_amdgcn_readlane((int)bl, gl);
+                if (srcs[k] >= 0 && (int)lane == srcs[k] && r_vb != 0u) {
+                    s.lqi = r_lqi; s.lqi_cnt = r_lqc;
+                    s.c0 = r_c0; s.c1 = r_c1; s.c2 = r_c2; s.b_prev = r_bp; s.b_last = r_bl;
+                    s.packetlen_cnt += (int)r_vb; s.payload_cnt += (int)r_vb;
+                    s.packet_byte = (int)r_bl;
+                    q += 64u * r_vb;
+                    fin = s.payload_cnt >= s.packetlen;
+                    stepped = true;
+                }
             }
         }
         if (alive && !stepped) {
