@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void zb_iir_scan(const double* __restrict__ Lb
 // a5-a6: lanes (IIR + Mueller & Mueller), chips out.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kMmWaves = 4;   // waves per zb_mm workgroup
-constexpr int kZRow = 41;          // per-lane z buffer: 8 samples of history + half a 64-sample tile, odd stride
+constexpr int kZRow = 40;          // z buffer of a wave: 8 samples of history + half a 64-sample tile, SAMPLE-major ([sample][lane]):
+                                   // a lane's bank is its lane number whatever its window offset -- lane-major rows (odd stride 41) put
+                                   // lanes at different offsets on the same banks: 537 against 177 cycles per 8-sample window at 12
+                                   // waves per CU (tools/lds_unaligned_probe.hip)
 // MMSE table in LDS as two float4 arrays (taps 0-3, taps 4-7 of every row): one ds_read_b128 each,
 // 16-B slot = row mod 16, so the 16 lanes of a read group spread over all slots
 constexpr uint32_t kMaxCand = 12;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     uint32_t* __restrict__ soft_n)
 {
     // kMmWaves independent waves per workgroup share one copy of the tap table (LDS decides how many
-    // waves a CU holds: 10.5 KB of rows per wave + 4.1 KB of taps per workgroup)
+    // waves a CU holds: 10 KB of z samples per wave + 4.1 KB of taps per workgroup)
     __shared__ float zb_all[kMmWaves * 64 * kZRow];
     __shared__ float4 tapsA[129], tapsB[129];
     const uint32_t l = threadIdx.x & 63u, w = blockIdx.x * kMmWaves + (threadIdx.x >> 6);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     uint32_t ii = 0, n_chips = 0, t_last = 0, c0 = 0, cand_n = 0;
     uint64_t hist = 0, hist_cand = 0;
     const bool tap = TAP && active && g == soft_lane && soft_chips != nullptr;
-    float* zrow = &zb[l * kZRow];
+    float* zcol = &zb[l];                                   // sample j of this lane at zcol[64 j]
     float zl[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) zl[k] = 0.0f;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
         for (uint32_t hb = 0; hb < 64u; hb += 32u) {
             if (hb < nz) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) zrow[k] = zl[k];
+                for (int k = 0; k < 8; k++) zcol[64 * k] = zl[k];
 #pragma unroll
                 for (uint32_t q = 0; q < 32u; q += 8u) {
                     if (hb + q < nz) {
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
                             const float x = pre[hb + q + k];
                             lp = alpha * (double)x + one_minus * lp;
                             const float z = x - (float)lp;
-                            zrow[8u + q + k] = z;
+                            zcol[64u * (8u + q + k)] = z;
                             zl[k] = z;
                             if constexpr (TAP) { if (tap && soft_z && r0 + hb + q + k < soft_cap) soft_z[r0 + hb + q + k] = z; }
                         }
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
             }
             const uint32_t staged = r0 + (nz < hb + 32u ? nz : hb + 32u);
             const uint32_t hi = staged < avail ? staged : avail;
-            const uint32_t zorg = r0 + hb - 8u;                      // sample held by zrow[0] (mod 2^32)
+            const uint32_t zorg = r0 + hb - 8u;                      // sample held by row 0 (mod 2^32)
             // windows must start before the core end and end inside what is staged
             const uint32_t lim = hi >= 8u ? (rce < hi - 7u ? rce : hi - 7u) : 0u;
             uint64_t dc = 0;
@@ -298,15 +301,15 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
                 while (ii < lim) {
                     const int imu = (int)rintf(mu * 128.0f);
                     const float4 ta = tapsA[imu], tb4 = tapsB[imu];
-                    const float* wv = &zrow[ii - zorg];                   // 8 consecutive samples
+                    const float* wv = &zcol[64u * (ii - zorg)];           // 8 consecutive samples, 64 floats apart
                     float acc = 0.0f;
-                    acc = __builtin_fmaf(ta.x, wv[7], acc);
-                    acc = __builtin_fmaf(ta.y, wv[6], acc);
-                    acc = __builtin_fmaf(ta.z, wv[5], acc);
-                    acc = __builtin_fmaf(ta.w, wv[4], acc);
-                    acc = __builtin_fmaf(tb4.x, wv[3], acc);
-                    acc = __builtin_fmaf(tb4.y, wv[2], acc);
-                    acc = __builtin_fmaf(tb4.z, wv[1], acc);
+                    acc = __builtin_fmaf(ta.x, wv[64 * 7], acc);
+                    acc = __builtin_fmaf(ta.y, wv[64 * 6], acc);
+                    acc = __builtin_fmaf(ta.z, wv[64 * 5], acc);
+                    acc = __builtin_fmaf(ta.w, wv[64 * 4], acc);
+                    acc = __builtin_fmaf(tb4.x, wv[64 * 3], acc);
+                    acc = __builtin_fmaf(tb4.y, wv[64 * 2], acc);
+                    acc = __builtin_fmaf(tb4.z, wv[64 * 1], acc);
                     acc = __builtin_fmaf(tb4.w, wv[0], acc);
                     const float o = acc;
                     if constexpr (TAP) { if (tap && n_chips + nc < soft_cap) soft_chips[n_chips + nc] = o; }

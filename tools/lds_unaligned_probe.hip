@@ -20,6 +20,11 @@ __global__ __launch_bounds__(256) void probe(const int* __restrict__ offs, float
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = p[k];
+        } else if (MODE == 2) {
+            // sample-major: the wave's 64 lanes side by side in every row: bank = lane whatever the lane's offset
+            const float* q = &buf[(l >> 6) * 64 * 41 + off * 64 + (l & 63)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = q[k * 64];
         } else {
             float4 a, b;
             const unsigned addr = (unsigned)(uintptr_t)p;
@@ -46,6 +51,10 @@ int main()
     unsigned long long c0 = 0, c1 = 0;
     hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, d_off, o0, iters, d_c); hipMemcpy(&c0, d_c, 8, hipMemcpyDeviceToHost);
     hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, d_off, o1, iters, d_c + 1); hipMemcpy(&c1, d_c + 1, 8, hipMemcpyDeviceToHost);
+    unsigned long long c2 = 0;
+    hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, d_off, o1, iters, d_c); hipMemcpy(&c2, d_c, 8, hipMemcpyDeviceToHost);
+    printf("sample-major rows (lane = bank): %.1f cycles per iteration\n", (double)c2 / iters);
+    hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, d_off, o1, iters, d_c + 1);
     if (hipDeviceSynchronize() != hipSuccess) { printf("unaligned ds_read_b128 FAULTED\n"); return 1; }
     std::vector<float> a(blocks * 256), b(blocks * 256);
     hipMemcpy(a.data(), o0, blocks * 1024, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o1, blocks * 1024, hipMemcpyDeviceToHost);
