@@ -10,7 +10,8 @@ from snout_amd.rx import SnoutRx
 from snout_amd import dist as sdist
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-x, expect, _ = bench.make_workload(int(1e9), seed=2, device=dev)
+tile, _ = bench.make_tile("cfg2", seed=2)
+x = bench.resident_capture(tile, int(1e9), seed=2, device=dev)
 rx = SnoutRx(proto=0, channel=37, device=0)
 
 
