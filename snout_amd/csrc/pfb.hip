@@ -750,6 +750,16 @@ extern "C" int snout_debug_pfb_stamps(unsigned long long* out, uint32_t n)
 }
 #endif
 
+// Zero of the discriminator rows behind the last channelizer tile (zb_mm reads whole lane tiles), all segments and
+// channels of a batch in ONE launch: one hipMemset2DAsync per segment was one small fill kernel per segment, each waiting
+// for a CU between the persistent launches (cfg #5: 16 fills per step).
+__global__ __launch_bounds__(256) void zb_zero_tails(float* __restrict__ d, uint64_t d_seg, uint64_t d_stride, uint64_t done, uint32_t rows)
+{
+    const uint32_t row = blockIdx.y % rows, seg = blockIdx.y / rows;
+    float* p = d + (uint64_t)seg * d_seg + (uint64_t)row * d_stride;
+    for (uint64_t i = done + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < d_stride; i += (uint64_t)gridDim.x * 256u) p[i] = 0.0f;
+}
+
 int PfbCtx::init(uint32_t M_)
 {
     M = M_;
@@ -853,8 +863,8 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
             // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
             const uint64_t done = (uint64_t)n_tiles * T16;
             if (done < zbt->d_stride)
-                for (uint32_t k = 0; k < count; k++)
-                    SNOUT_HIP(hipMemset2DAsync(zbt->d + (uint64_t)k * d_seg + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
+                hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zbt->d_stride - done, 256), 16u), M * count), dim3(256), 0, st,
+                                   zbt->d, d_seg, zbt->d_stride, done, M);
         }
         PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), zbt ? nullptr : d_y.as<float2>(), y_stride, nullptr, 0, zb};
         return pfb_spec_launch(16, zbt ? 2 : 0, fmt, 16, nwg * count, st, a);
@@ -872,8 +882,8 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
             // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
             const uint64_t done = (uint64_t)n_tiles * PfbGeom<16>::T;
             if (done < zbt->d_stride)
-                for (uint32_t k = 0; k < count; k++)
-                    SNOUT_HIP(hipMemset2DAsync(zbt->d + (uint64_t)k * d_seg + done, zbt->d_stride * 4u, 0, (zbt->d_stride - done) * 4u, M, st));
+                hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zbt->d_stride - done, 256), 16u), M * count), dim3(256), 0, st,
+                                   zbt->d, d_seg, zbt->d_stride, done, M);
 #define SNOUT_PFB_ZB(F) hipLaunchKernelGGL((pfb_channelize<16, true, F>), dim3(nwg * count), dim3(PfbGeom<16>::NT), 0, st, segs, n, n_out, \
             n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0, zb)
             if (fmt == kFmtSc8) SNOUT_PFB_ZB(kFmtSc8);
