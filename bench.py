@@ -656,13 +656,13 @@ def main():
                                                   "decoded_crc_ok_per_gpu", "min_expected_crc_ok_per_gpu", "parity_in_run")}
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
-            r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, 0, 1, seconds=args.seconds)
+            r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, 0, 1, seconds=args.seconds)
             others["cfg5"] = {f: r5[f] for f in CFG5_FIELDS}
             others["cfg5"]["note"] = "BASELINE.json configs[4] on one GPU; `--gpus N` carries its N-rank point the same way"
             out["other_workloads"] = others
         elif world > 1 and args.workload is None and not args.no_others:
             # configs[4] on the N ranks: segments round-robin, per-step RCCL all_gather of the records, dedup on rank 0
-            r5 = run_cfg5(max(3, min(args.steps, 5)), 3, device, rank, world, seconds=args.seconds)
+            r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, rank, world, seconds=args.seconds)
             if rank == 0:
                 out["other_workloads"] = {"cfg5": {f: r5[f] for f in CFG5_FIELDS}}
     if dist.is_initialized():
