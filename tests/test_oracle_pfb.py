@@ -45,3 +45,18 @@ def test_tone_lands_in_its_bin(oracle, M):
 def test_short_input_has_no_output(oracle):
     assert oracle.pfb_nout(639, 40) == 0 and oracle.pfb_nout(640, 40) == 1 and oracle.pfb_nout(660, 40) == 2
     assert oracle.pfb(np.zeros(100, np.complex64), 16).shape == (16, 0)
+
+
+def test_block_order_entry_differs_only_where_a_structural_zero_meets_a_non_finite_sample(oracle):
+    """`oracle_pfb_block_order` (what the experimental matrix-pipe FIR equals bit for bit) runs the FIR as banded-Toeplitz
+    matrix blocks: the same fmaf chain per output on finite input -- bit for bit --, but the blocks' structural zeros
+    multiply every sample of the block, so a NaN / Inf reaches outputs whose 16-tap window does not hold it."""
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(40 * 16 + 20 * 300) + 1j * rng.standard_normal(40 * 16 + 20 * 300)).astype(np.complex64)
+    a, b = oracle.pfb(x, 40), oracle.pfb(x, 40, block_order=True)
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    x[3000] = np.nan
+    a, b = oracle.pfb(x, 40), oracle.pfb(x, 40, block_order=True)
+    na, nb = np.isnan(a.view(np.float32)), np.isnan(b.view(np.float32))
+    assert na.any() and (nb | ~na).all() and nb.sum() > na.sum()          # the plain chain's NaNs are a strict subset
+    assert np.array_equal(a.view(np.uint32)[~nb], b.view(np.uint32)[~nb])

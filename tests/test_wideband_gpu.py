@@ -52,6 +52,45 @@ def test_channelizer_with_non_finite_samples(oracle, M, proto):
     assert 0 < np.isnan(want[0].view(np.float32)).sum() < want[0].size        # the NaNs stayed local
 
 
+_IMPL_SNIPPET = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import oracle_py
+from snout_amd.rx import SnoutRx
+from snout_amd._ffi import STAGE_CHAN_IQ
+M, proto, block = %(M)d, %(proto)d, %(block)r
+n = M * 16 + (M // 2) * 5000 + 3
+rng = np.random.default_rng(7)
+x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+x[n // 2] = np.nan
+want = oracle_py.pfb(x, M, block_order=block)
+with SnoutRx(proto=proto, n_channels=M, keep_channel_iq=True) as rx:
+    rx.process(x)
+    for slot in (0, 1, M // 2, M - 1):
+        got = rx.soft(STAGE_CHAN_IQ, slot).view(np.complex64)
+        assert got.size == want.shape[1]
+        nn = np.isnan(want[slot].view(np.float32))
+        assert np.array_equal(np.isnan(got.view(np.float32)), nn), slot
+        assert np.array_equal(got.view(np.uint32)[~nn], want[slot].view(np.uint32)[~nn]), slot
+print("equal")
+'''
+
+
+@pytest.mark.parametrize("impl,M,proto,block", [("valu", 40, 0, False), ("valu", 16, 1, False), ("spec12", 40, 0, False),
+                                                 ("mfma", 40, 0, True)])
+def test_the_kept_ab_partners_of_the_channelizer_are_bit_exact_too(impl, M, proto, block):
+    """`SNOUT_PFB_IMPL` (read when a handle is created) selects the kernels kept beside the shipped `pfb_spec`: round 2's
+    `pfb_channelize` (valu), the 12-wave layout (spec12) -- both the plain fmaf chain of `oracle_pfb` -- and the matrix-pipe
+    FIR (mfma) = `oracle_pfb_block_order` (banded-Toeplitz blocks of `v_mfma_f32_16x16x4_f32`; the snippet's input carries a
+    NaN, which is where the two orders differ), bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNOUT_PFB_IMPL=impl)
+    r = subprocess.run([sys.executable, "-c", _IMPL_SNIPPET % dict(root=root, M=M, proto=proto, block=block)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("equal"), r.stderr[-2000:]
+
+
 def test_channelizer_shorter_than_prototype():
     from snout_amd.rx import SnoutRx
     with SnoutRx(proto=0, n_channels=40) as rx:
