@@ -238,6 +238,14 @@ def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=No
             "compared": "every record field and byte, set equality after sorting by (channel, sample_index), against the CPU oracle"}
 
 
+def reserved_cus(world: int, fake: int) -> int:
+    """Compute units the channelizer's persistent grid leaves free when a record gather runs beside it (N > 1, or the
+    fake-world rehearsal): the RCCL kernels, the de-duplication and the record download then do not wait for a channelizer
+    launch to end.  8 = one per XCD; SNOUT_BENCH_RESERVED_CUS overrides."""
+    e = os.environ.get("SNOUT_BENCH_RESERVED_CUS")
+    return int(e) if e is not None else (8 if (world > 1 or fake > 1) else 0)
+
+
 # ------------------------------------------------------------------------------------------------
 # one workload on one handle, pipelined submit / collect
 # ------------------------------------------------------------------------------------------------
@@ -254,7 +262,11 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
     if fmt:
         x = quantise(x, fmt)
         torch.cuda.empty_cache()
-    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt)
+    # with a GPU exchange attached the records stay in device memory: the exchange packs them from there
+    on_dev = gather is not None and gather.on_gpu
+    rcus = reserved_cus(world, gather.fake if gather is not None else 0) if n_ch > 1 else 0
+    rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt, records_on_device=on_dev,
+                 reserved_cus=rcus)
 
     gathered = [0, 0]                   # exchanges finished on rank 0, records in the last one
 
@@ -265,12 +277,12 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
             gathered[1] = int(sum(len(v) for v in parts))
 
     def finish_one():
-        pk = rx.collect(copy=False)
+        pk = rx.collect(copy=False)                             # a count when the records stay on the device
         if gather is not None:
             # RCCL gather of this step's records to rank 0, overlapped with the next step
             if len(gather.inflight) == 2:
                 take_exchange()
-            gather.begin(int(pk.size))
+            gather.begin(int(pk if on_dev else pk.size))
             gather.append(pk, rx=rx)                            # packed from the device copy by one kernel: no upload
             gather.launch()
         return pk
@@ -351,12 +363,22 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
                        "peak_TFLOPs": FP32_PEAK_TFLOPS, "frac": fl / (k_avg * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
     if gather is not None:
         # the last timed step's exchange as rank 0 received it: every rank's records of that step
-        res["collective"] = "RCCL all_gather_into_tensor" if gather.backend == "nccl" else (
-            "%s all_gather_into_tensor" % gather.backend if gather.collective else "none (device copy)")
+        how = " all_gather (32-B headers) + gather to rank 0 (records)" if gather.to_root else " all_gather_into_tensor"
+        res["collective"] = ("RCCL" + how) if gather.backend == "nccl" else (
+            gather.backend + how if gather.collective else "none (device copy)")
         res["ranks_in_collective"] = gather.world
         res["records_on_rank0_last_step"] = gathered[1]
+        # every rank's records of the last timed step arrived: the exchange is deterministic, so the count rank 0 holds
+        # must EQUAL the sum of what the ranks decode from their captures (x the blocks of a fake-world rehearsal)
+        total = torch.tensor([len(local)], dtype=torch.int64, device=device if gather.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(total, group=gather.group)
         if rank == 0:
-            assert gathered[1] >= len(local) * (1 if world == 1 else 0), "rank 0 received fewer records than it decoded itself"
+            assert gathered[0] == (24 if n <= int(1.1e9) else 8) + warmup + steps, gathered
+            assert gathered[1] == int(total.item()) * (gather.fake or 1), (gathered, int(total.item()))
+        if gather.fake:
+            res["fake_world"] = gather.fake
+        res["reserved_cus"] = rcus
     rx.close()
     if parity_samples:
         res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt)
@@ -403,12 +425,18 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     import torch
     import torch.distributed as dist
     from snout_amd import dist as sdist
-    from snout_amd.sharded import ShardedScan, pump
+    from snout_amd.sharded import ShardedScan
     nb_rank, nz_rank = int(80e6 * seconds), int(32e6 * seconds)
+    on_gpu = (not dist.is_initialized()) or dist.get_backend(group) == "nccl"
+    # Every rank's segments of one step go to the library as ONE submission per scan (snout_rx_submit_batch_dev: up to 64
+    # segments run side by side in the same launches -- 48 segments of 2^24 samples at the rate of one 8e8-sample segment),
+    # the records stay in device memory (the exchange packs them from there) and the scans never drain between two steps.
+    fake = int(os.environ.get("SNOUT_BENCH_FAKE_WORLD", "0")) if world == 1 else 0
+    reserved = reserved_cus(world, fake)
     sb = ShardedScan(0, n_channels=40, seg_len=SEG, device=device.index, handles=int(os.environ.get("SNOUT_CFG5_HB", "1")),
-                     batch=int(os.environ.get("SNOUT_CFG5_BB", "6")))
+                     batch=int(os.environ.get("SNOUT_CFG5_BB", "48")), depth=3, records_on_device=on_gpu, reserved_cus=reserved)
     sz = ShardedScan(1, n_channels=16, seg_len=SEG, device=device.index, handles=int(os.environ.get("SNOUT_CFG5_HZ", "2")),
-                     batch=int(os.environ.get("SNOUT_CFG5_BZ", "8")))
+                     batch=int(os.environ.get("SNOUT_CFG5_BZ", "20")), depth=3, records_on_device=on_gpu, reserved_cus=reserved)
     # The virtual capture is N x `seconds` long and tile-periodic with a period that divides the
     # segment length, so every segment starts on a tile boundary: the overlap a rank reads behind its
     # segment i shows the same packets as the start of segment i+1 on the next rank (only the noise
@@ -431,32 +459,64 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
             return x[2 * lo:2 * (lo + (b - a))]
         caps.append((n_total, source, x))
     (nb, srcb, xb), (nz, srcz, xz) = caps
-    on_gpu = (not dist.is_initialized()) or dist.get_backend(group) == "nccl"
     gdev = device if on_gpu else None
     # 96-byte BTLE wire records: 24 + (2 + 63 + 3), the longest PDU the decoder can emit (a false access-address match on
-    # a data channel carries a 6-bit length)
-    gb = sdist.AsyncRecordGather(gdev, group, width=96, dedup_tol=0)
-    gz = sdist.AsyncRecordGather(gdev, group, width=160, dedup_tol=8 * 64 + 8)
-    results = []
+    # a data channel carries a 6-bit length).  The capacity is the same number on every rank (no collective to agree it).
+    hint_b, hint_z = nb_rank // 8000, nz_rank // 8000
+    gb = sdist.AsyncRecordGather(gdev, group, width=96, dedup_tol=0, cap=hint_b + hint_b // 4 + 1024, fake_world=fake, prealloc=6)
+    gz = sdist.AsyncRecordGather(gdev, group, width=160, dedup_tol=8 * 64 + 8, cap=hint_z + hint_z // 4 + 1024, fake_world=fake, prealloc=6)
+    results = {"b": None, "z": None}
+    trace = [] if os.environ.get("SNOUT_BENCH_TRACE") else None     # dev aid: where the host thread's time goes
+    sb.trace = sz.trace = trace
+    closed = {"b": 0, "z": 0}
+    launched = [0]
 
-    def one_step():
-        gb.begin(n_hint=nb_rank // 8000)
-        gz.begin(n_hint=nz_rank // 8000)
-        sb.start(nb, srcb, group, sink=gb)
-        sz.start(nz, srcz, group, sink=gz)
-        pump([sb, sz])
-        gb.launch()
-        gz.launch()
-        if len(gb.inflight) == 2:                   # the exchange of step i overlaps the kernels of step i+1
-            take()
+    def on_last(g, key):
+        g.close()
+        closed[key] += 1
+
+    def queue_step():
+        sb.start(nb, srcb, group, sink=gb, on_first=gb.begin, on_last=lambda: on_last(gb, "b"))
+        sz.start(nz, srcz, group, sink=gz, on_first=gz.begin, on_last=lambda: on_last(gz, "z"))
+
+    def pump_until(pred):
+        """Drive both scans from this one host thread until pred(): each submits while it has a free slot and collects
+        what has finished; the thread waits (in one scan's collect) only when neither can do either."""
+        while not pred():
+            live = [sc for sc in (sb, sz) if sc.active()]
+            if not any([sc.step(block=False) for sc in live]):
+                live[0].step()
 
     def take():
         b, z = gb.finish(views=True), gz.finish(views=True)      # zero-copy views of rank 0's pinned buffers
-        results.append((b[0], z[0]) if rank == 0 else None)
-        del results[:-1]
+        if rank == 0:
+            results["b"], results["z"] = b[0], z[0]
 
-    def drain():
-        while gb.inflight:
+    def launch_next():
+        """The exchanges of the oldest complete step, in the same order on every rank (the two gathers share the process
+        group).  Two exchanges of each are in flight: the exchange of step i overlaps the kernels of step i + 1."""
+        k = launched[0] + 1
+        pump_until(lambda: closed["b"] >= k and closed["z"] >= k)
+        t_a = time.perf_counter()
+        if len(gb.inflight) == 2:
+            take()
+        t_b = time.perf_counter()
+        gb.launch()
+        gz.launch()
+        launched[0] = k
+        if trace is not None:
+            trace.append(("take", t_b - t_a))
+            trace.append(("launch exchanges", time.perf_counter() - t_b))
+
+    def run_steps(k):
+        base = launched[0]
+        for i in range(k):
+            queue_step()                            # step i's submissions are queued behind step i - 1's: no drain between
+            if i >= 1:
+                launch_next()                       # step i - 1 complete on both scans -> its exchanges
+        while launched[0] < base + k:
+            launch_next()
+        while gb.inflight:                          # every step's records are on rank 0, de-duplicated
             take()
 
     def fence():
@@ -465,17 +525,23 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
             dist.barrier(group)
         torch.cuda.synchronize(device)
 
-    for _ in range(max(2, warmup)):
-        one_step()
-    drain()
-    results.clear()
+    run_steps(max(2, warmup))
     fence()
+    if trace is not None:
+        del trace[:]
     t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step()
-    drain()                                         # every step's records are on rank 0, de-duplicated
+    run_steps(steps)
     fence()
     dt = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        import collections
+        agg, cnt = collections.Counter(), collections.Counter()
+        for what, sec in trace:
+            agg[what] += sec
+            cnt[what] += 1
+        print("host trace over warm-up + %d steps (%.1f ms wall in the timed steps):" % (steps, dt * 1e3), file=sys.stderr)
+        for what, sec in agg.most_common():
+            print("  %-28s %5d calls %9.2f ms  (%.3f ms each)" % (what, cnt[what], sec * 1e3, sec * 1e3 / cnt[what]), file=sys.stderr)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
@@ -486,16 +552,18 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
         seen = torch.empty(dist.get_world_size(group), dtype=torch.int64, device=ids.device)
         dist.all_gather_into_tensor(seen, ids, group=group)
         assert sorted(seen.tolist()) == list(range(dist.get_world_size(group)))
-        collective = ("RCCL" if dist.get_backend(group) == "nccl" else dist.get_backend(group)) + " all_gather_into_tensor"
+        bk = "RCCL" if dist.get_backend(group) == "nccl" else dist.get_backend(group)
+        collective = bk + (" all_gather (32-B headers) + gather to rank 0 (records)" if gb.to_root else " all_gather_into_tensor")
         n_seen = int(seen.numel())
     else:
         collective, n_seen = "none (no process group: device copy)", 1
     res = None
     if rank == 0:
-        rb, rz = results[-1]
+        rb, rz = results["b"], results["z"]
         ok_b, ok_z = int(rb["crc_ok"].sum()), int(rz["crc_ok"].sum())
-        exp_b = int(0.9 * (nb // tb.size) * len(truth_b))
-        exp_z = int(0.8 * (nz // tz.size) * len(truth_z))
+        mult = fake or 1
+        exp_b = int(0.9 * (nb // tb.size) * len(truth_b)) * mult
+        exp_z = int(0.8 * (nz // tz.size) * len(truth_z)) * mult
         assert ok_b >= exp_b and ok_z >= exp_z, (ok_b, exp_b, ok_z, exp_z)
         key = (rb["channel"].astype(np.uint64) << np.uint64(48)) | rb["sample_index"]
         assert np.all(key[1:] > key[:-1]), "BTLE records on rank 0 are not sorted / de-duplicated"
@@ -506,16 +574,18 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
                "ms_per_step": dt / steps * 1e3, "steps": steps,
                "samples_per_gpu": nb_rank + nz_rank, "btle_samples_per_gpu": nb_rank, "zigbee_samples_per_gpu": nz_rank,
                "segments_per_gpu": len(sb._segs) + len(sz._segs), "segment_samples": SEG,
-               "segments_per_submission": {"btle": sb.batch, "zigbee": sz.batch},
+               "segments_per_submission": {"btle": sb.batch, "zigbee": sz.batch}, "reserved_cus": reserved,
                "value_per_gpu": total / dt / 1e6 / world, "collective": collective, "ranks_in_collective": n_seen,
                "device_of_rank0": int(device.index),
                "records_on_rank0": int(len(rb) + len(rz)), "decoded_crc_ok": ok_b + ok_z,
-               "min_expected_crc_ok": exp_b + exp_z, "decoded_pkts_per_s": (len(rb) + len(rz)) * steps / dt,
-               "sharding": "segment i -> rank i mod N; per step one all_gather of 96-B BTLE and one of 160-B "
+               "min_expected_crc_ok": exp_b + exp_z, "decoded_pkts_per_s": (len(rb) + len(rz)) / mult * steps / dt,
+               "sharding": "segment i -> rank i mod N; per step one exchange of 96-B BTLE and one of 160-B "
                            "802.15.4 records to rank 0 (%s), sort + de-duplication on rank 0's GPU, inside the "
-                           "timed region" % (("RCCL" if dist.get_backend(group) == "nccl" else dist.get_backend(group))
-                                             if dist.is_initialized() else "single rank: device copy"),
-               "algorithmic_bytes": 8.0 * (nb_rank + nz_rank) + 160.0 * (len(rb) + len(rz)) / world}
+                           "timed region" % (collective if dist.is_initialized() else "single rank: device copy"),
+               "algorithmic_bytes": 8.0 * (nb_rank + nz_rank) + 160.0 * (len(rb) + len(rz)) / mult / world}
+        if fake:
+            res["fake_world"] = {"blocks_on_rank0": fake, "note": "rehearsal at world size 1: rank 0 sorts, de-duplicates and downloads "
+                                 "%d copies of its own records per step (sample_index shifted per copy), as it will at N = %d" % (fake, fake)}
         res["achieved_GBps"] = res["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9
         res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
     sb.close()
@@ -525,8 +595,9 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     return res
 
 
-CFG5_FIELDS = ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu", "records_on_rank0", "decoded_crc_ok",
-               "min_expected_crc_ok", "frac", "value_per_gpu", "collective", "ranks_in_collective", "achieved_GBps", "sharding")
+CFG5_FIELDS = ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu", "segments_per_submission", "records_on_rank0",
+               "decoded_crc_ok", "min_expected_crc_ok", "frac", "value_per_gpu", "collective", "ranks_in_collective", "achieved_GBps",
+               "sharding", "fake_world", "reserved_cus")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -607,7 +678,9 @@ def main():
     else:
         n = int(args.samples or WORKLOADS[headline][3])
         # N > 1: the per-step record gather; SNOUT_BENCH_NCCL1=1 on a one-GPU box runs the same exchange on RCCL at world 1
-        gather = sdist.AsyncRecordGather(device, width=WORKLOADS[headline][4]) if (world > 1 or dist.is_initialized()) else None
+        fake = int(os.environ.get("SNOUT_BENCH_FAKE_WORLD", "0")) if world == 1 else 0
+        gather = (sdist.AsyncRecordGather(device, width=WORKLOADS[headline][4], fake_world=fake)
+                  if (world > 1 or dist.is_initialized() or fake > 1) else None)
         res, x = run_workload(headline, n, args.steps, args.warmup, device, rank, world, fmt=fmt, sync=args.sync,
                               gather=gather, keep_capture=True)
         if rank == 0:
@@ -630,8 +703,8 @@ def main():
                    "config": {"workload": res["workload"], "samples_per_gpu": n, "packets_per_gpu": res["packets_per_gpu"],
                               "decoded_pkts_per_s": res["decoded_pkts_per_s"],
                               "sharding": ("every rank its own segment, per-step %s gather of %d-B records to rank 0"
-                                           % (dist.get_backend(), WORKLOADS[headline][4])) if gather is not None else "single segment",
-                              **({k: res[k] for k in ("collective", "ranks_in_collective", "records_on_rank0_last_step")}
+                                           % (gather.backend, WORKLOADS[headline][4])) if gather is not None else "single segment",
+                              **({k: res[k] for k in ("collective", "ranks_in_collective", "records_on_rank0_last_step", "fake_world", "reserved_cus") if k in res}
                                  if gather is not None else {}),
                               "decoded_crc_ok_per_gpu": res["decoded_crc_ok_per_gpu"],
                               "min_expected_crc_ok_per_gpu": res["min_expected_crc_ok_per_gpu"],
@@ -657,14 +730,14 @@ def main():
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
             r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, 0, 1, seconds=args.seconds)
-            others["cfg5"] = {f: r5[f] for f in CFG5_FIELDS}
+            others["cfg5"] = {f: r5[f] for f in CFG5_FIELDS if f in r5}
             others["cfg5"]["note"] = "BASELINE.json configs[4] on one GPU; `--gpus N` carries its N-rank point the same way"
             out["other_workloads"] = others
         elif world > 1 and args.workload is None and not args.no_others:
             # configs[4] on the N ranks: segments round-robin, per-step RCCL all_gather of the records, dedup on rank 0
             r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, rank, world, seconds=args.seconds)
             if rank == 0:
-                out["other_workloads"] = {"cfg5": {f: r5[f] for f in CFG5_FIELDS}}
+                out["other_workloads"] = {"cfg5": {f: r5[f] for f in CFG5_FIELDS if f in r5}}
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

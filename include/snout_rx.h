@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define SNOUT_ABI_VERSION 1u
+/* 2: snout_rx_pack_last_records(skip, longest_dev), SNOUT_CFG_RECORDS_ON_DEVICE, batches of up to 64 segments,
+ *    snout_pkt.flags SNOUT_PKT_ZB_SEAM_DISAGREED, snout_zigbee_lane_shape (the default 802.15.4 lane shape depends on the
+ *    size of the call), the bench aid moved to snout_bench.h -- a client built against version 1 fails the handshake in
+ *    snout_rx_create instead of decoding a different frame set or missing a symbol */
+#define SNOUT_ABI_VERSION 2u
 
 /* protocols (snout/core/protocols/__init__.py:2-27 names them BTLE / ZIGBEE) */
 #define SNOUT_PROTO_BTLE   0u
@@ -49,6 +53,11 @@ extern "C" {
                                          needed for the SNOUT_STAGE_CHAN_IQ tap).  Default: the
                                          channelizer feeds the BTLE bit planes / the 802.15.4
                                          discriminator rows directly                              */
+#define SNOUT_CFG_RECORDS_ON_DEVICE 2u /* pipelined entry points: the records of a collected segment stay in
+                                         device memory; snout_rx_collect_view hands out their COUNT and a NULL
+                                         pointer, snout_rx_last_records_dev / snout_rx_pack_last_records the
+                                         records.  For a consumer on the GPU (the multi-GPU gather): without it
+                                         every submission's records are also downloaded to pinned host memory */
 
 /* error codes */
 #define SNOUT_OK          0
@@ -89,8 +98,13 @@ typedef struct snout_rx_cfg {
     uint32_t flags;           /* SNOUT_CFG_* bits                                                */
     uint32_t sample_format;   /* SNOUT_FMT_* of every iq pointer handed to this handle (0 = cf32)  */
     uint32_t batch_segments;  /* segments one snout_rx_submit_batch_dev call may carry; 0 -> 1.
-                                 > 1: wideband handles (n_channels > 1) only, at most 8           */
-    uint32_t reserved[1];     /* zero                                                            */
+                                 > 1: wideband handles (n_channels > 1) only, at most 64          */
+    uint32_t reserved_cus;    /* wideband handles: compute units the channelizer's persistent grid leaves free
+                                 (0: none).  The channelizer holds one 16-wave workgroup with all of a CU's LDS
+                                 on every CU it runs on, so nothing else runs beside it there: a caller with
+                                 concurrent work on other streams that must not wait for a launch to end --
+                                 the RCCL kernels and the record download of a multi-GPU gather -- reserves
+                                 a few CUs (8 = one per XCD costs the channelizer 3 %)                */
 } snout_rx_cfg;
 
 /* snout_pkt.flags of an 802.15.4 record: the clock recovery runs in lanes (cfg.zb_core); where one lane's timing
@@ -155,13 +169,15 @@ int  snout_rx_process_dev(snout_rx* h, const void* iq_dev, uint64_t n_samples,
 /* Pipelined form: up to three segments may be in flight.  submit enqueues every kernel of a segment
  * on hip_stream and returns without waiting; collect waits for the oldest submitted segment and
  * hands out its records (collect_view: a pointer into the handle's pinned buffer, valid until three
- * more submits).  The record D2H of segment i runs on an internal copy stream and overlaps the
+ * more submits; NULL and the count alone with SNOUT_CFG_RECORDS_ON_DEVICE).  The record D2H of segment i runs on an internal copy stream and overlaps the
  * kernels of segment i+1.  iq_dev must stay valid and unchanged until its collect returns. */
 int  snout_rx_submit_dev  (snout_rx* h, const void* iq_dev, uint64_t n_samples,
                            uint64_t first_sample_index, void* hip_stream);
 /* Several capture segments of EQUAL length as one submission (handle created with cfg.batch_segments
  * >= count): short segments leave most of the GPU idle inside the lane-serial 802.15.4 kernels (a 2^24-
- * sample wideband segment is 256 waves of clock recovery on 256 CUs), a batch runs them side by side.
+ * sample wideband segment is 256 waves of clock recovery on 256 CUs) and pay the channelizer's prologue per
+ * launch; a batch runs them side by side in the same launches (48 segments of 2^24 samples at the rate of one
+ * 8e8-sample segment).
  * The records of the batch come out of ONE collect, ordered by (segment, channel, sample_index), each
  * with its own segment's first_sample_index[k] added; records whose sample_index is below
  * min_sample_index[k] are dropped (NULL: none) -- a sharded scan leaves what a segment finds in its
@@ -195,13 +211,27 @@ int  snout_rx_profile(snout_rx* h, snout_rx_prof* out);
 int  snout_rx_profile_history(snout_rx* h, float* ms, uint32_t cap, uint32_t* n_out);
 
 /* Multi-GPU gather (no reference counterpart: the reference has one radio): copy the
- * device copy of the records of the segment collected last into an exchange buffer on the device, in the
- * wire format = the first `width` bytes (a multiple of 16, 32..160) of every 160-byte record, on
- * `hip_stream`.  Records with sample_index < own_from (found in a segment's pre-roll: another segment
- * reports them) get sample_index = 2^62 and are dropped by the gather's sort.  *n_packed = records
- * written (<= dst_cap; SNOUT_EOVERFLOW if the segment had more). */
+ * device copy of the records of the segment collected last, from record `skip` on, into an exchange buffer
+ * on the device, in the wire format = the first `width` bytes (a multiple of 16, 32..160) of every 160-byte
+ * record, on `hip_stream`.  Records with sample_index < own_from (found in a segment's pre-roll: another
+ * segment reports them) get sample_index = 2^62 and are dropped by the gather's sort.  longest_dev (may be
+ * NULL): a device uint64 raised (atomic max) to the largest snout_pkt.len packed, so that a consumer that
+ * never sees the records on the host can still refuse a record its wire format would truncate.
+ * *n_packed = records written (<= dst_cap; SNOUT_EOVERFLOW if the segment had more behind `skip`). */
 int  snout_rx_pack_last_records(snout_rx* h, void* dst_dev, uint64_t dst_cap, uint32_t width, uint64_t own_from,
-                                void* hip_stream, uint64_t* n_packed);
+                                uint64_t skip, void* longest_dev, void* hip_stream, uint64_t* n_packed);
+
+/* Rank 0 of the gather: sort the gathered wire records (`blocks` rank blocks of `cap` record slots of `width` bytes,
+ * block b valid up to min(counts_dev[b * counts_stride], cap)) by (proto, channel, sample_index) and drop what the overlaps
+ * of neighbouring capture segments found twice -- same (proto, channel), sample_index at most `tol` apart and, for
+ * tol > 0 (802.15.4: every receiver locks at its own phase), equal length and bytes; records disowned by
+ * snout_rx_pack_last_records (sample_index = 2^62) are dropped.  The kept records go to out_dev (room for blocks * cap),
+ * their number to *n_keep_dev; everything is enqueued on hip_stream, nothing waits.  work_dev: scratch of
+ * snout_records_dedup_workspace(blocks, cap) bytes.  (The host statement of the same rule: snout_amd/dist.py::dedup_records.) */
+size_t snout_records_dedup_workspace(uint32_t blocks, uint64_t cap);
+int    snout_records_dedup(const void* rows_dev, uint32_t width, uint32_t blocks, uint64_t cap, const int64_t* counts_dev,
+                           uint32_t counts_stride, uint32_t tol, void* out_dev, uint64_t* n_keep_dev, void* work_dev,
+                           size_t work_bytes, void* hip_stream);
 
 /* Host-side formatters for the two consumer contracts. */
 /* btle_rx stdout grammar (snout/core/message.py:214-215,226-236). Returns bytes written

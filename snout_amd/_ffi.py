@@ -14,8 +14,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNOUT_RX_LIB") or os.path.join(_HERE, "lib", "libsnout_rx.so")   # override: A/B builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PROTO_BTLE, PROTO_ZIGBEE = 0, 1
+CFG_KEEP_CHANNEL_IQ, CFG_RECORDS_ON_DEVICE = 1, 2
 STAGE_BTLE_BITS, STAGE_CHAN_IQ, STAGE_ZB_DISCRIM, STAGE_ZB_DCREMOVED, STAGE_ZB_CHIPS = range(5)
 
 EXPORTS = [
@@ -26,6 +27,7 @@ EXPORTS = [
     "snout_zigbee_center_hz", "snout_btle_center_hz", "snout_btle_rf_to_channel",
     "snout_strerror", "snout_last_error", "snout_abi_version", "snout_bench_hbm_read_gbps",
     "snout_rx_pack_last_records", "snout_rx_submit_batch_dev", "snout_rx_poll", "snout_zigbee_lane_shape",
+    "snout_records_dedup", "snout_records_dedup_workspace",
 ]
 
 
@@ -41,7 +43,7 @@ class RxCfg(C.Structure):
                 ("access_addr", C.c_uint32), ("crc_init", C.c_uint32),
                 ("chip_threshold", C.c_uint32), ("zb_core", C.c_uint32), ("zb_warmup", C.c_uint32),
                 ("max_hits", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
-                ("sample_format", C.c_uint32), ("batch_segments", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("sample_format", C.c_uint32), ("batch_segments", C.c_uint32), ("reserved_cus", C.c_uint32)]
 
 
 class RxProf(C.Structure):
@@ -119,8 +121,12 @@ def load() -> C.CDLL:
     lib.snout_strerror.restype = C.c_char_p
     lib.snout_last_error.argtypes = []
     lib.snout_last_error.restype = C.c_char_p
-    lib.snout_rx_pack_last_records.argtypes = [vp, vp, u64, C.c_uint32, u64, vp, C.POINTER(u64)]
+    lib.snout_rx_pack_last_records.argtypes = [vp, vp, u64, C.c_uint32, u64, u64, vp, vp, C.POINTER(u64)]
     lib.snout_rx_pack_last_records.restype = C.c_int
+    lib.snout_records_dedup_workspace.argtypes = [C.c_uint32, u64]
+    lib.snout_records_dedup_workspace.restype = C.c_size_t
+    lib.snout_records_dedup.argtypes = [vp, C.c_uint32, C.c_uint32, u64, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, vp]
+    lib.snout_records_dedup.restype = C.c_int
     lib.snout_bench_hbm_read_gbps.argtypes = [vp, u64, C.c_uint32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.snout_bench_hbm_read_gbps.restype = C.c_int
     lib.snout_abi_version.argtypes = []

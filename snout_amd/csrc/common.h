@@ -61,7 +61,7 @@ struct DevBuf {
 // Two of them let the record D2H of segment i overlap the kernels of segment i+1.
 // A batch of capture segments of equal length handled as ONE call (snout_rx_submit_batch_dev): segment k
 // owns the channel slots [k slots_per_seg, (k + 1) slots_per_seg).  By value in kernel arguments.
-constexpr uint32_t kMaxBatch = 8;
+constexpr uint32_t kMaxBatch = 64;
 struct SegBatch {
     uint64_t first[kMaxBatch];          // channel-sample index of the segment's first sample
     uint64_t min_index[kMaxBatch];      // records that start before it are dropped (0: keep all)
@@ -117,7 +117,8 @@ struct BtleCtx {
 
 // records.hip: the first `width` bytes of n 160-byte records -> dst (n x width bytes); records whose
 // sample_index is below own_from get sample_index = 2^62 ("disowned": the gather's sort drops them)
-int launch_pack_records(const snout_pkt* src, uint64_t n, void* dst, uint32_t width, uint64_t own_from, hipStream_t st);
+// longest_dev (optional): a device uint64 that receives, by atomicMax, the largest snout_pkt.len packed
+int launch_pack_records(const snout_pkt* src, uint64_t n, void* dst, uint32_t width, uint64_t own_from, void* longest_dev, hipStream_t st);
 
 void launch_tile_reduce(const uint32_t* in, const uint32_t* n_ptr, uint32_t n_fixed, uint32_t n_limit,
                         uint32_t clamp, uint32_t* tile_sums, uint32_t* tile_over, uint32_t n_tiles,
@@ -178,12 +179,15 @@ struct PfbCtx {
     uint32_t M = 0;
     uint64_t n_out = 0, y_stride = 0;
     uint32_t grid_blocks = 0;        // persistent grid; 0 = what is RESIDENT at once (see PfbCtx::run), else SNOUT_PFB_BLOCKS
-    bool last_spec = false;          // the last launch was a pfb_spec.hip kernel (profile names)
+    uint32_t n_cus = 256, reserved_cus = 0;     // the device's compute units; those the grid leaves free (cfg.reserved_cus)
+    enum { kKernelSpec = 0, kKernelSpec12, kKernelMfma, kKernelValu };
+    int last_kernel = kKernelSpec;   // the kernel the last launch actually ran (profile names)
     uint32_t small_tiles = 0;        // SNOUT_PFB_SMALL40 / SNOUT_PFB_SMALL16: launches with fewer tiles than this use pfb.hip's kernels (several workgroups per CU
                                      // leave room for other streams' kernels; pfb_spec.hip's one 16-wave workgroup per CU does not)
     int impl = 4;                    // SNOUT_PFB_IMPL, M = 40 kernel: 0 valu = pfb.hip, 1 mfma / 2 spec16 = pfb_mfma.hip with its FIR on the matrix / vector pipe, 3 spec12 / 4 spec = pfb_spec.hip with 12 / 16 waves
     DevBuf d_proto, d_tw, d_tw5, d_y;
-    int init(uint32_t M);
+    uint32_t min_item_tiles = 48;    // SNOUT_PFB_MIN_ITEM: fewest tiles of one workgroup's range when a batch is cut finer than one range per CU
+    int init(uint32_t M, uint32_t n_cus = 256, uint32_t reserved_cus = 0);
     void destroy();
     uint64_t n_out_for(uint64_t n) const;
     // planes16 != null (M = 40): fused BTLE mode, hard bits go straight into the bit planes

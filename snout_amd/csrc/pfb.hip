@@ -729,10 +729,9 @@ void pfb_channelize(SNOUT_PFB_ARGS)
 }
 
 // =============================================================================================
-// Host side
+// Host side: launcher only (the channelizer context lives in pfb_ctx.hip).  This file is an A/B partner of the shipped
+// pfb_spec.hip kernels: it is linked into libsnout_rx_ab.so (make ab), not into the product library.
 // =============================================================================================
-static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
-
 #ifdef SNOUT_PFB_T128
 #define SNOUT_PFB_DYN_LDS(MM) ((MM) == 40 ? (size_t)PfbGeom<40>::T * 41u * 8u : (size_t)0)
 #else
@@ -750,150 +749,26 @@ extern "C" int snout_debug_pfb_stamps(unsigned long long* out, uint32_t n)
 }
 #endif
 
-// Zero of the discriminator rows behind the last channelizer tile (zb_mm reads whole lane tiles), all segments and
-// channels of a batch in ONE launch: one hipMemset2DAsync per segment was one small fill kernel per segment, each waiting
-// for a CU between the persistent launches (cfg #5: 16 fills per step).
-__global__ __launch_bounds__(256) void zb_zero_tails(float* __restrict__ d, uint64_t d_seg, uint64_t d_stride, uint64_t done, uint32_t rows)
-{
-    const uint32_t row = blockIdx.y % rows, seg = blockIdx.y / rows;
-    float* p = d + (uint64_t)seg * d_seg + (uint64_t)row * d_stride;
-    for (uint64_t i = done + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < d_stride; i += (uint64_t)gridDim.x * 256u) p[i] = 0.0f;
-}
+uint32_t pfb_valu_tile(uint32_t M) { return M == 40 ? (uint32_t)PfbGeom<40>::T : (uint32_t)PfbGeom<16>::T; }
 
-int PfbCtx::init(uint32_t M_)
+// mode: 0 channel IQ, 1 BTLE planes (M = 40), 2 802.15.4 rows (M = 16); grid = workgroups (segs.wgs_per_seg per segment)
+int pfb_valu_launch(uint32_t M, int mode, int fmt, uint32_t grid, hipStream_t st, const PfbMfArgs& a,
+                    const float* twM, const float* tw5)
 {
-    M = M_;
-    if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
-    if (const char* e = getenv("SNOUT_PFB_IMPL")) impl = strcmp(e, "valu") == 0 ? 0 : (strcmp(e, "mfma") == 0 ? 1 : (strcmp(e, "spec16") == 0 ? 2 : (strcmp(e, "spec12") == 0 ? 3 : 4)));
-    if (const char* e = getenv(M_ == 40 ? "SNOUT_PFB_SMALL40" : "SNOUT_PFB_SMALL16")) small_tiles = (uint32_t)atoi(e);
-    if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
-    const float* proto = M == 40 ? kPfbProto40 : kPfbProto16;
-    const float* tw = M == 40 ? kTw40 : kTw16;
-    if (int rc = d_proto.ensure(M * 16 * 4)) return rc;
-    if (int rc = d_tw.ensure(2 * M * 4)) return rc;
-    if (int rc = d_tw5.ensure(10 * 4)) return rc;
-    SNOUT_HIP(hipMemcpy(d_proto.p, proto, M * 16 * 4, hipMemcpyHostToDevice));
-    SNOUT_HIP(hipMemcpy(d_tw.p, tw, 2 * M * 4, hipMemcpyHostToDevice));
-    SNOUT_HIP(hipMemcpy(d_tw5.p, kTw5, 10 * 4, hipMemcpyHostToDevice));
-    return 0;
-}
-
-void PfbCtx::destroy()
-{
-    d_proto.release(); d_tw.release(); d_tw5.release(); d_y.release();
-}
-
-uint64_t PfbCtx::n_out_for(uint64_t n) const
-{
-    const uint64_t L = (uint64_t)M * 16u, D = M / 2u;
-    return n >= L ? (n - L) / D + 1u : 0u;
-}
-
-int PfbCtx::run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16, uint64_t plane_stride,
-                const PfbZbTarget* zbt, int fmt)
-{
-    return run_batch(&d_iq, 1, n, st, planes16, plane_stride, 0, zbt, 0, 0, fmt);
-}
-
-// `count` segments of n samples each in ONE launch: segment k reads iqs[k] and writes its bit planes
-// planes_seg uint16 further than segment k - 1 (fused BTLE), its discriminator rows / sub-block sums
-// d_seg floats / S_seg doubles further (fused 802.15.4).  A launch per 2^24-sample segment spends a third of
-// its time in prologues and in the last, partly filled round of tiles; four segments per launch do not.
-int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStream_t st, uint16_t* planes16,
-                      uint64_t plane_stride, uint64_t planes_seg, const PfbZbTarget* zbt, uint64_t d_seg,
-                      uint64_t S_seg, int fmt)
-{
-    if (count == 0 || count > kMaxBatch || (count > 1 && !planes16 && !zbt)) {
-        set_last_error("channelizer batch of %u segments (1..%u; more than one only in the fused modes)", count, kMaxBatch);
-        return SNOUT_EINVAL;
-    }
-    PfbSegs segs{};
-    for (uint32_t k = 0; k < count; k++) segs.x[k] = iqs[k];
-    segs.planes_seg = planes_seg; segs.d_seg = d_seg; segs.S_seg = S_seg;
-    n_out = n_out_for(n);
-    y_stride = (n_out + 64 + 1) & ~1ull;      // even: channel rows stay 16-byte aligned
-    if (!planes16 && !zbt) { if (int rc = d_y.ensure(y_stride * M * 8u)) return rc; }
-    PfbZbOut zb{};
-    if (zbt) zb = PfbZbOut{zbt->d, zbt->d_stride, zbt->S, zbt->nsb, zbt->atan_tab, zbt->iir_w};
-    if (n_out == 0) return 0;
-#define SNOUT_PFB_F(MM, FU, F, Y, YS, PL, PS)                                                          \
-    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(nwg * count), dim3(PfbGeom<MM>::NT), SNOUT_PFB_DYN_LDS(MM), st, segs, n, n_out, \
-                       n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), Y, YS, PL, PS, zb)
-#define SNOUT_PFB(MM, FU, Y, YS, PL, PS)                                                               \
+#define SNOUT_PFB_F(MM, FU, F)                                                                          \
+    hipLaunchKernelGGL((pfb_channelize<MM, FU, F>), dim3(grid), dim3(PfbGeom<MM>::NT), SNOUT_PFB_DYN_LDS(MM), st, a.segs, a.n, a.n_out, \
+                       a.n_tiles, a.tiles_per_wg, a.proto, twM, tw5, a.y, a.y_stride, a.planes16, a.plane_stride, a.zb)
+#define SNOUT_PFB(MM, FU)                                                                               \
     do {                                                                                              \
-        if (fmt == kFmtSc8) SNOUT_PFB_F(MM, FU, kFmtSc8, Y, YS, PL, PS);                              \
-        else if (fmt == kFmtSc16) SNOUT_PFB_F(MM, FU, kFmtSc16, Y, YS, PL, PS);                       \
-        else SNOUT_PFB_F(MM, FU, kFmtCf32, Y, YS, PL, PS);                                            \
+        if (fmt == kFmtSc8) SNOUT_PFB_F(MM, FU, kFmtSc8);                                              \
+        else if (fmt == kFmtSc16) SNOUT_PFB_F(MM, FU, kFmtSc16);                                       \
+        else SNOUT_PFB_F(MM, FU, kFmtCf32);                                                            \
     } while (0)
-    // Persistent workgroups, each walks a contiguous range of tiles: the grid must be what is RESIDENT at
-    // once, or the rest runs as a second round on a nearly empty chip.  M = 40: a workgroup is 5 waves,
-    // at 4 wave slots per SIMD (105..128 VGPRs) the hardware's cyclic wave placement fits exactly TWO of
-    // them per CU, not the three that 16 slots / 5 waves suggests (census with s_memrealtime stamps,
-    // tools/pfb_stamps.py: 512 of 768 workgroups started at once, 2 on every CU, the other 256 after
-    // them; a 514-workgroup grid takes 5.9 ms instead of 3.8).
-    const bool small = (uint64_t)cdiv(n_out, 128u) * count < small_tiles;      // tiles of the whole launch
-    last_spec = impl != 0 && !small && (M == 16 || impl >= 3);
-    if (M == 40 && impl != 0 && !small) {
-        // pfb_mfma.hip: one 16-wave workgroup per CU (FIR on the matrix pipe beside the FFT waves), tiles of 128
-        const uint32_t n_tiles = cdiv(n_out, 128u);
-        const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
-        const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
-        segs.wgs_per_seg = nwg;
-        PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), planes16 ? nullptr : d_y.as<float2>(), y_stride,
-                    planes16, plane_stride, PfbZbOut{}};
-        if (impl >= 3) return pfb_spec_launch(40, planes16 != nullptr ? 1 : 0, fmt, impl == 3 ? 12 : 16, nwg * count, st, a);
-        return pfb_mfma_launch(40, planes16 != nullptr, fmt, impl == 1 ? 0 : 1, nwg * count, st, a);
-    } else if (M == 40) {
-        const uint32_t n_tiles = cdiv(n_out, PfbGeom<40>::T);
-        const uint32_t blocks40 = std::max(1u, (grid_blocks ? grid_blocks : 512u) / count);     // per segment
-        const uint32_t tpw = cdiv(n_tiles, blocks40), nwg = cdiv(n_tiles, tpw);
-        segs.wgs_per_seg = nwg;
-        if (planes16)
-            SNOUT_PFB(40, true, (float2*)nullptr, (uint64_t)0, planes16, plane_stride);
-        else
-            SNOUT_PFB(40, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
-    } else if (impl != 0 && !small) {
-        // pfb_spec.hip, M = 16: FIR waves beside FFT + discriminator waves, one 16-wave workgroup per CU
-        const uint32_t T16 = pfb_spec_tile(16);
-        const uint32_t n_tiles = cdiv(n_out, T16);
-        const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : 256u) / count);
-        const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
-        segs.wgs_per_seg = nwg;
-        if (zbt) {
-            // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
-            const uint64_t done = (uint64_t)n_tiles * T16;
-            if (done < zbt->d_stride)
-                hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zbt->d_stride - done, 256), 16u), M * count), dim3(256), 0, st,
-                                   zbt->d, d_seg, zbt->d_stride, done, M);
-        }
-        PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), zbt ? nullptr : d_y.as<float2>(), y_stride, nullptr, 0, zb};
-        return pfb_spec_launch(16, zbt ? 2 : 0, fmt, 16, nwg * count, st, a);
-    } else {
-        const uint32_t n_tiles = cdiv(n_out, PfbGeom<16>::T);
-        // 256-thread workgroups: four per CU fit (<= 128 VGPRs, 29 KB LDS).  The fused 802.15.4 variant keeps
-        // to three per CU although it would fit four since it is built without the SLP vectorizer (126
-        // registers): one segment at a time 1 024 workgroups are 6 % faster (1.94 -> 1.83 ms per 3.2e8
-        // samples), but in a pipelined scan the chain's other kernels then find no free wave slots beside
-        // the persistent grid, and the step gets 4 % slower (cfg #4: 3.15 -> 3.31 ms; cfg #5 likewise).
-        const uint32_t blocks16 = std::max(1u, (grid_blocks ? grid_blocks : (zbt ? 768u : 1024u)) / count);     // 4-wave workgroups place evenly
-        const uint32_t tpw = cdiv(n_tiles, blocks16), nwg = cdiv(n_tiles, tpw);
-        segs.wgs_per_seg = nwg;
-        if (zbt) {
-            // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
-            const uint64_t done = (uint64_t)n_tiles * PfbGeom<16>::T;
-            if (done < zbt->d_stride)
-                hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zbt->d_stride - done, 256), 16u), M * count), dim3(256), 0, st,
-                                   zbt->d, d_seg, zbt->d_stride, done, M);
-#define SNOUT_PFB_ZB(F) hipLaunchKernelGGL((pfb_channelize<16, true, F>), dim3(nwg * count), dim3(PfbGeom<16>::NT), 0, st, segs, n, n_out, \
-            n_tiles, tpw, d_proto.as<float>(), d_tw.as<float>(), d_tw5.as<float>(), (float2*)nullptr, (uint64_t)0, (uint16_t*)nullptr, (uint64_t)0, zb)
-            if (fmt == kFmtSc8) SNOUT_PFB_ZB(kFmtSc8);
-            else if (fmt == kFmtSc16) SNOUT_PFB_ZB(kFmtSc16);
-            else SNOUT_PFB_ZB(kFmtCf32);
-#undef SNOUT_PFB_ZB
-        } else {
-            SNOUT_PFB(16, false, d_y.as<float2>(), y_stride, (uint16_t*)nullptr, (uint64_t)0);
-        }
-    }
+    if (M == 40 && mode == 1) SNOUT_PFB(40, true);
+    else if (M == 40 && mode == 0) SNOUT_PFB(40, false);
+    else if (M == 16 && mode == 2) SNOUT_PFB(16, true);
+    else if (M == 16 && mode == 0) SNOUT_PFB(16, false);
+    else return SNOUT_EINVAL;
 #undef SNOUT_PFB
 #undef SNOUT_PFB_F
     SNOUT_HIP(hipGetLastError());

@@ -150,7 +150,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // So does the (tiny) BTLE tail of a small pipelined segment: the two cross-stream hand-overs cost
     // more than the ~50 us of kernels they would overlap (48 wideband segments of 2^24 samples: 12.3
     // -> 9.9 ms); behind a 1e9-sample front end the separate stream is worth 5 %.
-    const uint64_t ch_samples = (h->wide ? h->pfb.n_out_for(s.n_in) * h->cfg.n_channels : s.n_in);
+    const uint64_t ch_samples = (h->wide ? h->pfb.n_out_for(s.n_in) * h->cfg.n_channels : s.n_in) * s.segs.count;
     const bool inline_tail = h->sync_call || (h->cfg.proto == SNOUT_PROTO_BTLE && ch_samples < (1ull << 26));
     hipStream_t tail = inline_tail ? st : h->tail_stream;
     // (the first kernel's start event ev_k0 also marks the start of the segment: every event on the
@@ -226,6 +226,7 @@ static int enqueue_copy(snout_rx* h, ResultSlot& s, uint64_t spec)
     if (!h->sync_call) SNOUT_HIP(hipStreamWaitEvent(cs, s.ev_compute, 0));
     SNOUT_HIP(hipMemcpyAsync(s.h_totals, s.d_totals.p, 16, hipMemcpyDeviceToHost, cs));
     s.spec_copied = 0;
+    if (h->cfg.flags & SNOUT_CFG_RECORDS_ON_DEVICE) spec = 0;       // the caller takes them from the device copy
     if (spec) {
         const uint64_t room = s.d_out.cap / sizeof(snout_pkt);
         spec = spec < room ? spec : room;
@@ -359,7 +360,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
             chs[b] = c.proto == SNOUT_PROTO_BTLE ? (uint16_t)snout_btle_rf_to_channel((b + 20u) % 40u)
                                                  : (uint16_t)(11u + (b + 8u) % 16u);
         if (c.taps_per_branch != 16) { set_last_error("taps_per_branch must be 16"); goto fail; }
-        rc = h->pfb.init(M);
+        rc = h->pfb.init(M, (uint32_t)prop.multiProcessorCount, c.reserved_cus);
         if (rc) goto fail;
         rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments)
                                          : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
@@ -543,6 +544,12 @@ int snout_rx_collect_view(snout_rx* h, const snout_pkt** recs, uint64_t* n_out)
     h->pending--;
     if (int rc = finish_slot(h, s)) return rc;
     const uint64_t np = s.n_pkts;
+    if (h->cfg.flags & SNOUT_CFG_RECORDS_ON_DEVICE) {
+        // the records stay in device memory (snout_rx_last_records_dev / snout_rx_pack_last_records): only the count is handed out
+        note_last(h, s);
+        *n_out = np;
+        return SNOUT_OK;
+    }
     if (np > s.spec_copied) {
         // the speculative copy was short: fetch the rest (d_out of this slot is still intact)
         std::vector<snout_pkt> keep;
@@ -574,16 +581,16 @@ int snout_rx_last_records_dev(snout_rx* h, const snout_pkt** recs_dev, uint64_t*
 }
 
 int snout_rx_pack_last_records(snout_rx* h, void* dst_dev, uint64_t dst_cap, uint32_t width, uint64_t own_from,
-                               void* hip_stream, uint64_t* n_packed)
+                               uint64_t skip, void* longest_dev, void* hip_stream, uint64_t* n_packed)
 {
     if (!h || !n_packed || (!dst_dev && dst_cap) || width < 32u || width > sizeof(snout_pkt) || (width & 15u)) return SNOUT_EINVAL;
     *n_packed = 0;
     if (!h->last) { set_last_error("no collected segment"); return SNOUT_EINVAL; }
-    const uint64_t np = h->last->n_pkts;
+    const uint64_t np = h->last->n_pkts > skip ? h->last->n_pkts - skip : 0u;
     const uint64_t m = np < dst_cap ? np : dst_cap;
     SNOUT_HIP(hipSetDevice(h->device));
     if (m) {
-        if (int rc = launch_pack_records(h->last->d_out.as<snout_pkt>(), m, dst_dev, width, own_from, (hipStream_t)hip_stream))
+        if (int rc = launch_pack_records(h->last->d_out.as<snout_pkt>() + skip, m, dst_dev, width, own_from, longest_dev, (hipStream_t)hip_stream))
             return rc;
     }
     *n_packed = m;
@@ -598,7 +605,9 @@ int snout_rx_collect(snout_rx* h, snout_pkt* out, uint64_t cap, uint64_t* n_out)
     if (int rc = snout_rx_collect_view(h, &recs, &np)) return rc;
     *n_out = np;
     const uint64_t m = np < cap ? np : cap;
-    if (m) memcpy(out, recs, m * sizeof(snout_pkt));
+    if (m && !recs) {                   // SNOUT_CFG_RECORDS_ON_DEVICE: downloaded on request only
+        SNOUT_HIP(hipMemcpy(out, h->last->d_out.p, m * sizeof(snout_pkt), hipMemcpyDeviceToHost));
+    } else if (m) memcpy(out, recs, m * sizeof(snout_pkt));
     if (np > cap) { set_last_error("output capacity %llu < %llu packets", (unsigned long long)cap,
                                    (unsigned long long)np); return SNOUT_EOVERFLOW; }
     return SNOUT_OK;
@@ -685,12 +694,12 @@ int snout_rx_profile(snout_rx* h, snout_rx_prof* out)
     out->n_hits = s.h_totals[0];
     out->dominant_launches = 1;
     if (h->wide) {
-        if (h->pfb.last_spec)                            // which kernel PfbCtx::run_batch launched
-            snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_spec%u", h->pfb.M);
-        else if (h->pfb.impl != 0 && h->pfb.M == 40 && h->pfb.impl < 3)
-            snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_mfma<40>");
-        else
-            snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M);
+        // the kernel PfbCtx::run_batch actually launched
+        switch (h->pfb.last_kernel) {
+            case PfbCtx::kKernelMfma: snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_mfma<%u>", h->pfb.M); break;
+            case PfbCtx::kKernelValu: snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_channelize<%u>", h->pfb.M); break;
+            default: snprintf(out->dominant_name, sizeof(out->dominant_name), "pfb_spec%u", h->pfb.M); break;
+        }
     } else if (h->cfg.proto == SNOUT_PROTO_ZIGBEE) {
         out->dominant_launches = 2;
         snprintf(out->dominant_name, sizeof(out->dominant_name), "zb_discrim..zb_walk");

@@ -172,15 +172,17 @@ class AsyncRecordGather:
     """Pipelined gather of packet records to rank 0.
 
     One exchange = ``begin()``, any number of ``append()`` (one per collected segment), ``launch()``;
-    ``start(rec, dev_ptr)`` is the three in one.  ``launch()`` enqueues, on a side stream, ONE
-    fixed-size ``all_gather`` (RCCL over xGMI with the nccl backend) and, on rank 0, an optional
-    device-side sort + dedup of the gathered block (``dedup_tol`` not None) and its download into
-    pinned host memory; ``finish()`` waits for the oldest launched exchange and returns the records
-    (rank 0) or None.  Two exchanges may be in flight, so the exchange of step i overlaps the
-    kernels of step i+1.
+    ``start(rec, dev_ptr)`` is the three in one.  ``launch()`` enqueues, on a side stream, the exchange
+    (RCCL over xGMI with the nccl backend) and, on rank 0, an optional device-side sort + dedup of the
+    gathered block (``dedup_tol`` not None) and its download into pinned host memory; ``finish()`` waits
+    for the oldest launched exchange and returns the records (rank 0) or None.  Two exchanges may be in
+    flight, so the exchange of step i overlaps the kernels of step i+1.
 
-    Every rank sends ``cap`` record slots preceded by a header slot holding its TRUE count.  A rank
-    with more records than slots sends what fits and keeps the rest; since every rank sees every
+    The exchange is two collectives of fixed size: an ``all_gather`` of one 32-byte header per rank (true
+    count, longest record) and a ``gather`` of ``cap`` record slots per rank TO RANK 0 -- only rank 0
+    needs the records (round 3 sent every rank's block to every rank: 8 x the bytes into seven ranks that
+    dropped them; ``SNOUT_GATHER=all`` keeps that form, one ``all_gather_into_tensor``, for comparison).
+    A rank with more records than slots sends what fits and keeps the rest; since every rank sees every
     header, all ranks find out together in ``finish()``, exchange the remainders in a second
     (synchronous) all_gather and raise the capacity for the exchanges that follow -- overflow is a
     collective decision, never one rank raising while the others sit in the collective.
@@ -188,11 +190,18 @@ class AsyncRecordGather:
     ``width`` < 160 gathers only the first ``width`` bytes of each record (a BTLE record is at most 24 + 2 + 63 + 3
     bytes: 96 holds every record the decoder can emit, also a false access-address match with a 6-bit length on a
     data channel; the rest is zero by construction).  A record that does not fit is a ValueError -- like the
-    overflow a collective one: its length travels in the header slot and every rank raises in ``finish()``.
+    overflow a collective one: its length travels in the header and every rank raises in ``finish()``.
+
+    ``fake_world`` = F > 1 (world size 1 only; ``SNOUT_BENCH_FAKE_WORLD``): a rehearsal of rank 0's load at F ranks
+    on one GPU -- after the real exchange rank 0's block is copied F - 1 more times (sample_index shifted by r 2^40 so
+    that nothing de-duplicates away) and rank 0 sorts, de-duplicates and downloads F blocks, as it will at N = F.
     """
 
+    HDR = 32        # header bytes per rank: count, longest record (host appends), longest record (device appends), spare
+
     def __init__(self, device=None, group=None, width: int = REC, dedup_tol: Optional[int] = None,
-                 cap: int = 0):
+                 cap: int = 0, fake_world: int = 0, prealloc: int = 0):
+        import os
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -201,41 +210,65 @@ class AsyncRecordGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # with a process group the exchange is a real collective even at world size 1 (a one-GPU box then runs the
-        # RCCL all_gather path that N > 1 runs); without one it is a device copy
+        # RCCL path that N > 1 runs); without one it is a device copy
         self.collective = dist.is_initialized()
+        self.to_root = os.environ.get("SNOUT_GATHER", "root") != "all"
+        self.root = dist.get_global_rank(group, 0) if (self.collective and group is not None) else 0
         self.on_gpu = self.backend == "nccl" or (self.backend == "none" and device is not None
                                                  and torch.device(device).type == "cuda")
         self.device = torch.device(device) if self.on_gpu else torch.device("cpu")
         self.width = int(width)
-        assert 24 < self.width <= REC and self.width % 8 == 0
+        assert 32 <= self.width <= REC and self.width % 8 == 0
         self.dedup_tol = dedup_tol
+        self.fake = int(fake_world) if (fake_world and fake_world > 1 and self.world == 1) else 0
+        self.blocks = self.fake or self.world       # record blocks rank 0 holds after an exchange
         self.cap = int(cap)             # capacity new exchanges are sized for (0: agreed at the first launch)
-        self.slots = [None, None]
-        self.next = 0
-        self.cur = None
+        self.pool = []                  # finished slots, oldest first: reused once another has finished (views stay valid until then)
+        self.cur = None                 # the open exchange (appends go here)
+        self.closed = []                # complete, not yet launched
         self.inflight = []
         # high priority: the short exchange must not queue behind the next segment's kernels
         self.stream = torch.cuda.Stream(device=self.device, priority=-1) if self.on_gpu else None
         self.dtype = wire_dtype(self.width)
+        # exchange buffers made up front (needs cap): one being filled, one complete, two in flight, one whose views the
+        # consumer still reads -- pinned allocations of tens of MB do not belong into the first steps of a scan
+        self.spare = [self._make_slot(self.cap) for _ in range(int(prealloc))] if (prealloc and self.cap) else []
 
     # ---- buffers -------------------------------------------------------------------------------
     def _make_slot(self, cap: int) -> dict:
         torch = self.torch
-        W, pin = self.width, self.on_gpu
-        send = torch.zeros((cap + 1) * W, dtype=torch.uint8, device=self.device)
-        recv = torch.zeros(self.world * (cap + 1) * W, dtype=torch.uint8, device=self.device)
-        hdr = torch.zeros(self.world, dtype=torch.int64, pin_memory=pin)
+        W, pin, B = self.width, self.on_gpu, self.blocks
+        head = torch.zeros(4, dtype=torch.int64, device=self.device)                 # this rank's header, on the device
+        send = torch.zeros(cap * W, dtype=torch.uint8, device=self.device)
+        heads = torch.zeros((B, 4), dtype=torch.int64, device=self.device)           # every rank's header
+        recv = torch.zeros(B * cap * W, dtype=torch.uint8, device=self.device) if (self.rank == 0 or not self.to_root) else None
         host = n_host = None
         if self.rank == 0:
-            rows = self.world * cap + 1 if self.dedup_tol is not None else self.world * (cap + 1)
+            rows = B * cap + 1 if self.dedup_tol is not None else B * cap
             host = torch.zeros(rows * W, dtype=torch.uint8, pin_memory=pin)
             n_host = torch.zeros(1, dtype=torch.int64, pin_memory=pin)
         ev = torch.cuda.Event() if self.on_gpu else None
         up = torch.cuda.Event() if self.on_gpu else None
-        hdr2 = torch.zeros((self.world, 2), dtype=torch.int64, pin_memory=pin)      # every rank's (count, longest record)
-        hsend = torch.zeros(W, dtype=torch.uint8, pin_memory=pin)                    # this rank's header slot, staged
-        return dict(cap=cap, send=send, recv=recv, hdr=hdr, hdr2=hdr2, hsend=hsend, host=host, n_host=n_host, ev=ev, up=up,
-                    fill=0, n=0, rest=[], wide=0)
+        hdr2 = torch.zeros((B, 4), dtype=torch.int64, pin_memory=pin)                # every rank's header, downloaded
+        hsend = torch.zeros(2, dtype=torch.int64, pin_memory=pin)                    # this rank's (count, longest on host), staged
+        work = out = n_keep = None
+        if self.rank == 0 and self.dedup_tol is not None and self._native():
+            # the library's sort + duplicate removal (snout_records_dedup): its scratch, its output, its count
+            work = torch.empty(self._lib.snout_records_dedup_workspace(B, cap), dtype=torch.uint8, device=self.device)
+            out = torch.empty(B * cap * W, dtype=torch.uint8, device=self.device)
+            n_keep = torch.zeros(1, dtype=torch.int64, device=self.device)
+        return dict(work=work, out=out, n_keep=n_keep, cap=cap, send=send, head=head, heads=heads, recv=recv, hdr2=hdr2, hsend=hsend, host=host, n_host=n_host,
+                    ev=ev, up=up, fill=0, n=0, rest=[], wide=0)
+
+    def _native(self) -> bool:
+        """The de-duplication runs in libsnout_rx.so (a handful of launches) when the exchange is on a GPU; the torch
+        formulation of the same rule (:func:`dedup_device`, ~65 launches) serves CPU tensors (gloo tests)."""
+        if not (self.on_gpu and self.width % 16 == 0):
+            return False
+        if getattr(self, "_lib", None) is None:
+            from . import _ffi
+            self._lib = _ffi.load()
+        return True
 
     def _agree(self, n: int) -> int:
         t = self.torch.tensor([n], dtype=self.torch.int64, device=self.device)
@@ -250,39 +283,55 @@ class AsyncRecordGather:
     def begin(self, n_hint: int = 0) -> None:
         """Open an exchange.  The first one agrees the capacity (collective: 1.25x the largest
         ``n_hint`` of any rank + 1024); later ones reuse or grow their slot without a collective."""
-        if len(self.inflight) >= 2:
-            raise RuntimeError("two gathers in flight: finish() one first")
-        assert self.cur is None, "launch() the open exchange first"
+        assert self.cur is None, "close() or launch() the open exchange first"
         if self.cap == 0:
             m = self._agree(int(n_hint))
             self.cap = m + m // 4 + 1024
-        k = self.next
-        self.next ^= 1
-        if self.slots[k] is None or self.slots[k]["cap"] < self.cap:
-            self.slots[k] = self._make_slot(self.cap)
-        slot = self.slots[k]
+        slot = None
+        if self.spare and self.spare[-1]["cap"] >= self.cap:
+            slot = self.spare.pop()
+        elif len(self.pool) >= 2:         # the oldest finished slot: another exchange has finished since (its views were valid until then)
+            slot = self.pool.pop(0)
+            if slot["cap"] < self.cap:
+                slot = None
+        if slot is None:
+            slot = self._make_slot(self.cap)
         slot["fill"], slot["n"], slot["rest"], slot["wide"] = 0, 0, [], 0
+        with self._ctx():
+            slot["head"].zero_()            # [2]: raised by the pack kernels of device-side appends
         self.cur = slot
 
-    def append(self, rec: np.ndarray, dev_ptr: int = 0, own_from: int = 0, rx=None) -> None:
+    def append(self, rec, dev_ptr: int = 0, own_from: int = 0, rx=None) -> None:
         """Add the records of one collected segment.  ``rx``: the receiver handle that just collected
         them -- on a GPU its library then packs them from the device copy into the exchange buffer with
-        ONE kernel launch (``snout_rx_pack_last_records``); ``dev_ptr`` (SnoutRx.last_records_device())
-        does the same with torch operations.  Records with sample_index < ``own_from`` belong to another
-        segment and are dropped."""
+        ONE kernel launch (``snout_rx_pack_last_records``); ``rec`` may then be the record COUNT alone (a
+        handle created with ``records_on_device=True``: nothing was downloaded).  ``dev_ptr``
+        (SnoutRx.last_records_device()) does the same with torch operations.  Records with sample_index <
+        ``own_from`` belong to another segment and are dropped."""
         torch = self.torch
         slot = self.cur
-        n = int(rec.size)
+        counted = not isinstance(rec, np.ndarray)           # a count: the records are on the device only
+        n = int(rec) if counted else int(rec.size)
         if n == 0:
             return
+        if counted and not (self.on_gpu and rx is not None):
+            raise TypeError("a record count needs the handle that holds the records (rx=) and a GPU exchange")
         # a record longer than the wire format holds: NOT an exception here (the other ranks would sit in the
-        # all_gather): its length travels in the header slot and every rank raises together in finish()
-        slot["wide"] = max(slot["wide"], int(rec["len"].max()))
+        # collective): its length travels in the header and every rank raises together in finish()
+        if not counted:
+            slot["wide"] = max(slot["wide"], int(rec["len"].max()))
         W = self.width
         slot["n"] += n
         take = min(n, slot["cap"] - slot["fill"])
         if take < n:                                    # keeps its true count in the header; finish() resends
-            r = np.ascontiguousarray(rec[take:]).copy()
+            if counted:                                 # rare: fetch what did not fit from the device copy
+                ptr, have = rx.last_records_device()
+                assert have == n
+                raw = _device_bytes(torch, ptr + take * REC, (n - take) * REC, self.device).cpu().numpy()
+                r = raw.view(PKT_DTYPE).copy()
+                slot["wide"] = max(slot["wide"], int(r["len"].max()))
+            else:
+                r = np.ascontiguousarray(rec[take:]).copy()
             if own_from:
                 r = r[r["sample_index"] >= own_from]
                 slot["n"] -= (n - take) - r.size
@@ -290,12 +339,13 @@ class AsyncRecordGather:
         if take == 0:
             return
         if self.on_gpu and rx is not None:
-            dst = slot["send"].data_ptr() + (1 + slot["fill"]) * W
-            rx.pack_last_records(dst, take, W, int(own_from), self.stream.cuda_stream)
+            dst = slot["send"].data_ptr() + slot["fill"] * W
+            rx.pack_last_records(dst, take, W, int(own_from), self.stream.cuda_stream,
+                                 longest_ptr=(slot["head"].data_ptr() + 16) if counted else 0)
             slot["fill"] += take
             return
         with self._ctx():
-            view = slot["send"][(1 + slot["fill"]) * W:(1 + slot["fill"] + take) * W].view(take, W)
+            view = slot["send"][slot["fill"] * W:(slot["fill"] + take) * W].view(take, W)
             if self.on_gpu and dev_ptr:
                 view.copy_(_device_bytes(torch, dev_ptr, take * REC, self.device).view(take, REC)[:, :W])
             else:
@@ -309,29 +359,62 @@ class AsyncRecordGather:
                 si.copy_(torch.where(si < own_from, torch.full_like(si, int(_DROP)), si))
         slot["fill"] += take
 
-    def launch(self) -> None:
-        torch = self.torch
+    def close(self) -> None:
+        """The open exchange is complete (no collective is issued: ranks may close at different times)."""
         slot = self.cur
         self.cur = None
-        W, cap = self.width, slot["cap"]
         with self._ctx():
-            # header slot: true count and longest record appended.  Staged in pinned memory (an asynchronous copy); the
-            # slot is reused two launches later, after finish() has waited for this exchange's event.
-            slot["hsend"][:16].view(torch.int64).copy_(torch.tensor([slot["n"], slot["wide"]], dtype=torch.int64))
-            slot["send"][:W].copy_(slot["hsend"], non_blocking=True)
+            # header: true count and longest record appended on the host.  Staged in pinned memory (an asynchronous copy);
+            # the slot is reused only after finish() has waited for this exchange's event.
+            slot["hsend"][0], slot["hsend"][1] = slot["n"], slot["wide"]
+            slot["head"][:2].copy_(slot["hsend"], non_blocking=True)
             if self.on_gpu:
                 slot["up"].record(self.stream)       # the callers' record buffers may be reused after this
+        self.closed.append(slot)
+
+    def launch(self) -> None:
+        """Issue the collectives of the oldest complete exchange (closing the open one first if none is waiting).
+        Every rank has to launch its exchanges -- of every gather that shares the process group -- in the same order."""
+        torch = self.torch
+        if not self.closed:
+            self.close()
+        if len(self.inflight) >= 2:
+            raise RuntimeError("two gathers in flight: finish() one first")
+        slot = self.closed.pop(0)
+        W, cap, B = self.width, slot["cap"], self.blocks
+        with self._ctx():
+            heads = slot["heads"]
             if self.collective:
-                self.dist.all_gather_into_tensor(slot["recv"], slot["send"], group=self.group)
+                self.dist.all_gather_into_tensor(heads[:self.world].view(-1), slot["head"], group=self.group)
+                if self.to_root:
+                    outs = list(slot["recv"].view(B, cap * W)[:self.world].unbind(0)) if self.rank == 0 else None
+                    self.dist.gather(slot["send"], outs, dst=self.root, group=self.group)
+                else:
+                    self.dist.all_gather_into_tensor(slot["recv"][:self.world * cap * W], slot["send"], group=self.group)
             else:
-                slot["recv"].copy_(slot["send"])
-            blocks = slot["recv"].view(self.world, (cap + 1) * W)
-            heads = blocks[:, :16].contiguous().view(torch.int64).reshape(self.world, 2)      # one kernel, one download
+                heads[0].copy_(slot["head"])
+                slot["recv"][:cap * W].copy_(slot["send"])
+            if self.fake and self.rank == 0:
+                # rehearsal: rank 0 holds F blocks as it will at N = F (its own, shifted so that nothing de-duplicates away)
+                blk = slot["recv"].view(B, cap, W)
+                blk[1:].copy_(blk[0:1].expand(B - 1, cap, W))
+                si = blk.view(torch.int64)[1:, :, 0]
+                si.add_((torch.arange(1, B, device=self.device, dtype=torch.int64) << 40).view(B - 1, 1))
+                heads[1:].copy_(heads[0:1].expand(B - 1, 4))
             counts = heads[:, 0]
             slot["hdr2"].copy_(heads, non_blocking=True)         # every rank learns every count and every longest record
             if self.rank == 0:
-                if self.dedup_tol is not None:
-                    rows = blocks[:, W:].reshape(self.world * cap, W).view(torch.int64)
+                if self.dedup_tol is not None and slot["work"] is not None:
+                    from . import _ffi
+                    import ctypes as C
+                    _ffi.check(self._lib.snout_records_dedup(
+                        C.c_void_p(slot["recv"].data_ptr()), W, B, cap, C.c_void_p(heads.data_ptr()), 4, int(self.dedup_tol),
+                        C.c_void_p(slot["out"].data_ptr()), C.c_void_p(slot["n_keep"].data_ptr()),
+                        C.c_void_p(slot["work"].data_ptr()), slot["work"].numel(), C.c_void_p(self.stream.cuda_stream)))
+                    slot["host"][:B * cap * W].copy_(slot["out"], non_blocking=True)
+                    slot["n_host"].copy_(slot["n_keep"], non_blocking=True)
+                elif self.dedup_tol is not None:
+                    rows = slot["recv"].view(B * cap, W).view(torch.int64)
                     out, n_keep = dedup_device(torch, rows, torch.clamp(counts, max=cap), cap, int(self.dedup_tol))
                     slot["host"].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
                     slot["n_host"].copy_(n_keep, non_blocking=True)
@@ -351,7 +434,7 @@ class AsyncRecordGather:
         """Block until the record buffers handed to append() have been read (they may be views of
         a receiver's pinned result slot that the next submit will overwrite)."""
         if self.on_gpu:
-            for slot in self.inflight:
+            for slot in self.closed + self.inflight:
                 slot["up"].synchronize()
 
     def _exchange_rest(self, slot, counts) -> Optional[np.ndarray]:
@@ -382,17 +465,18 @@ class AsyncRecordGather:
         """Records of the oldest launched exchange (rank 0; None elsewhere), in the wire dtype
         (:func:`widen_records` pads them back to ``PKT_DTYPE``).  With ``dedup_tol`` set: one sorted,
         duplicate-free array.  Otherwise ``views=True`` returns a list with one zero-copy view per
-        rank into the pinned receive buffer (valid until the slot is reused two launches later)
+        rank into the pinned receive buffer (valid until the next finish())
         instead of one concatenated array -- at 8 ranks the concatenation is a 30 MB host copy."""
         if not self.inflight:
             return None
         slot = self.inflight.pop(0)
+        self.pool.append(slot)
         if self.on_gpu:
             slot["ev"].synchronize()
-        W, cap = self.width, slot["cap"]
+        W, cap, B = self.width, slot["cap"], self.blocks
         h2 = slot["hdr2"].numpy()
-        counts = [int(c) for c in h2[:, 0]]
-        widest = int(h2[:, 1].max())
+        counts = [int(c) for c in h2[:self.world, 0]]
+        widest = int(h2[:self.world, 1:3].max())
         if widest > W - 24:             # every rank sees the same headers: every rank raises, none is left in a collective
             raise ValueError(f"a rank appended a record of {widest} bytes: it does not fit the {W}-byte wire format")
         rest = self._exchange_rest(slot, counts) if max(counts) > cap else None
@@ -403,9 +487,10 @@ class AsyncRecordGather:
             out = slot["host"].numpy()[:n * W].view(self.dtype)
             if rest is not None:        # rare: merge the remainder with the host rule
                 out = dedup_records(np.concatenate([out, rest]), tol=int(self.dedup_tol))
-            return [out] if views else out.copy()     # a view is valid until the slot is reused two launches later
-        host = slot["host"].numpy().reshape(self.world, (cap + 1) * W)
-        parts = [host[r, W:(min(counts[r], cap) + 1) * W].view(self.dtype) for r in range(self.world)]
+            return [out] if views else out.copy()     # a view is valid until the next finish()
+        host = slot["host"].numpy().reshape(B, cap * W)
+        allc = [int(c) for c in h2[:, 0]]
+        parts = [host[r, :min(allc[r], cap) * W].view(self.dtype) for r in range(B)]
         if rest is not None:
             parts.append(rest)
         if views:

@@ -34,16 +34,21 @@ class SnoutRx:
                  access_addr: int = 0, crc_init: int = 0, chip_threshold: int = 0,
                  taps_per_branch: int = 0, zb_core: int = 0, zb_warmup: int = 0,
                  max_hits: int = 0, device: int = -1, keep_channel_iq: bool = False,
-                 sample_format: int = 0, batch_segments: int = 1):
+                 sample_format: int = 0, batch_segments: int = 1, records_on_device: bool = False,
+                 reserved_cus: int = 0):
         self._lib = _ffi.load()
         cfg = _ffi.RxCfg(abi_version=_ffi.ABI_VERSION, proto=proto, n_channels=n_channels,
                          taps_per_branch=taps_per_branch, channel=channel,
                          access_addr=access_addr, crc_init=crc_init,
                          chip_threshold=chip_threshold, zb_core=zb_core, zb_warmup=zb_warmup,
                          max_hits=max_hits, device=device)
-        cfg.flags = 1 if keep_channel_iq else 0            # SNOUT_CFG_KEEP_CHANNEL_IQ: unfused wideband kernels (CHAN_IQ tap)
+        # SNOUT_CFG_KEEP_CHANNEL_IQ: unfused wideband kernels (CHAN_IQ tap); SNOUT_CFG_RECORDS_ON_DEVICE: collect() hands out
+        # counts, the records stay on the device for pack_last_records() / last_records_device()
+        cfg.flags = (_ffi.CFG_KEEP_CHANNEL_IQ if keep_channel_iq else 0) | (_ffi.CFG_RECORDS_ON_DEVICE if records_on_device else 0)
+        self.records_on_device = bool(records_on_device)
         cfg.sample_format = int(sample_format)             # FMT_CF32 / FMT_SC8 / FMT_SC16
         cfg.batch_segments = int(batch_segments)           # segments one submit_batch() may carry
+        cfg.reserved_cus = int(reserved_cus)               # CUs the channelizer's grid leaves to other streams
         self.batch_segments = max(1, int(batch_segments))
         self.sample_format = int(sample_format)
         self._h = C.c_void_p()
@@ -172,12 +177,15 @@ class SnoutRx:
             _ffi.check(rc)
         return rc == 1
 
-    def collect(self, copy: bool = True) -> np.ndarray:
+    def collect(self, copy: bool = True):
         """Records of the oldest submitted segment. ``copy=False``: a view of the handle's pinned
-        buffer, valid until three more submits."""
+        buffer, valid until three more submits.  A handle created with ``records_on_device=True`` returns the
+        record COUNT (an int): the records stay in device memory."""
         ptr = C.c_void_p()
         n = C.c_uint64(0)
         _ffi.check(self._lib.snout_rx_collect_view(self._h, C.byref(ptr), C.byref(n)))
+        if self.records_on_device:
+            return int(n.value)          # the records stay on the device (pack_last_records / last_records_device)
         if n.value == 0:
             return np.zeros(0, dtype=PKT_DTYPE)
         buf = (C.c_uint8 * (n.value * PKT_DTYPE.itemsize)).from_address(ptr.value)
@@ -192,12 +200,15 @@ class SnoutRx:
         _ffi.check(self._lib.snout_rx_last_records_dev(self._h, C.byref(ptr), C.byref(n)))
         return (ptr.value or 0), int(n.value)
 
-    def pack_last_records(self, dst_ptr: int, dst_cap: int, width: int, own_from: int, stream: int) -> int:
-        """Pack the device copy of the last collected segment's records into an exchange buffer on the
-        device (wire format: the first ``width`` bytes of each record), on ``stream``; one launch."""
+    def pack_last_records(self, dst_ptr: int, dst_cap: int, width: int, own_from: int, stream: int,
+                          skip: int = 0, longest_ptr: int = 0) -> int:
+        """Pack the device copy of the last collected segment's records (from record ``skip`` on) into an exchange
+        buffer on the device (wire format: the first ``width`` bytes of each record), on ``stream``; one launch.
+        ``longest_ptr``: device uint64 raised to the largest record length packed."""
         n = C.c_uint64(0)
-        _ffi.check(self._lib.snout_rx_pack_last_records(self._h, C.c_void_p(dst_ptr), dst_cap, width, own_from,
-                                                        C.c_void_p(stream), C.byref(n)), allow_overflow=True)
+        _ffi.check(self._lib.snout_rx_pack_last_records(self._h, C.c_void_p(dst_ptr), dst_cap, width, own_from, skip,
+                                                        C.c_void_p(longest_ptr or None), C.c_void_p(stream), C.byref(n)),
+                   allow_overflow=True)
         return int(n.value)
 
     def soft(self, stage: int, channel_slot: int = 0, cap: int = 0) -> np.ndarray:

@@ -29,12 +29,13 @@ class ShardedScan:
     """``handles`` > 1 keeps that many receiver handles, each on its own stream, and deals the
     segments to them in turn: short segments leave most of the GPU idle inside the latency-bound
     kernels (a 2^24-sample Zigbee segment is 128 waves of clock recovery), and independent handles
-    let consecutive segments overlap.  ``batch`` > 1 (wideband 802.15.4) hands that many segments of
-    equal length to the library as ONE submission (``snout_rx_submit_batch_dev``): they run side by
-    side inside the same kernels instead of one behind the other."""
+    let consecutive segments overlap.  ``batch`` > 1 (wideband handles) hands that many segments of
+    equal length to the library as ONE submission (``snout_rx_submit_batch_dev``, up to 64): they run side by
+    side inside the same kernels instead of one behind the other.  ``records_on_device=True`` (scans that
+    feed a GPU ``sink``): the handles keep their records in device memory and ``collect`` hands out counts."""
 
     def __init__(self, proto: int, n_channels: int = 1, channel: int = 37, seg_len: int = 1 << 24,
-                 device: int = -1, handles: int = 1, batch: int = 1, **rx_kw):
+                 device: int = -1, handles: int = 1, batch: int = 1, depth: int = 2, **rx_kw):
         self.proto = proto
         self.n_channels = n_channels
         self.decim = n_channels // 2 if n_channels > 1 else 1
@@ -46,12 +47,14 @@ class ShardedScan:
         pre = 0 if proto == PROTO_BTLE else ZIGBEE_PREROLL_CH * self.decim
         self.preroll = (pre + step - 1) // step * step                # in input samples
         self.batch = max(1, int(batch))
+        self.depth = max(1, min(3, int(depth)))                       # submissions in flight per handle (the library holds 3)
         if self.batch > 1:
             rx_kw = dict(rx_kw, batch_segments=self.batch)
         self.rxs = [SnoutRx(proto=proto, channel=channel, n_channels=n_channels, device=device, **rx_kw)
                     for _ in range(max(1, handles))]
         self.rx = self.rxs[0]
         self._streams = None
+        self._segs = []
 
     def close(self):
         for rx in self.rxs:
@@ -64,14 +67,26 @@ class ShardedScan:
         return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world, self.preroll)
 
     # ---- a scan as a sequence of steps, so that several scans can share a GPU (run_concurrent)
-    def start(self, n_total: int, source: Callable[[int, int], "object"], group=None, sink=None) -> None:
-        """``sink``: an :class:`snout_amd.dist.AsyncRecordGather` with an open exchange; every collected
-        segment's records are then appended to it straight from device memory (no host concatenation)
-        instead of being kept in ``_parts``."""
+    def start(self, n_total: int, source: Callable[[int, int], "object"], group=None, sink=None,
+              on_first=None, on_last=None) -> None:
+        """Queue the submissions of one capture.  May be called again while submissions of the capture queued before
+        are still in flight (a continuous scan: the GPU never drains between two captures); they are submitted and
+        collected in order.
+
+        ``sink``: an :class:`snout_amd.dist.AsyncRecordGather`; every collected segment's records are appended to it
+        straight from device memory (no host concatenation) instead of being kept in ``_parts``.  ``on_first()`` is
+        called before the first collected submission of THIS capture is appended (open the exchange there),
+        ``on_last()`` after the last one (launch it)."""
+        import collections
         import torch
         if self._streams is None:
             dev = torch.device("cuda", torch.cuda.current_device())
             self._streams = [torch.cuda.Stream(device=dev) for _ in self.rxs]
+            self._jobs = collections.deque()        # submissions not yet submitted
+            self._flight = collections.deque()      # submitted, not yet collected
+            self._next = self._done = 0             # submissions submitted / collected since the handles were made
+            self._appended = [None] * len(self.rxs)
+            self._parts = []
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())               # the capture was produced on this stream
         for st in self._streams:
@@ -81,73 +96,90 @@ class ShardedScan:
         world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         rank = tdist.get_rank(group) if tdist.is_initialized() else 0
         # channel-sample index below which segment j's records belong to the segment before it
-        self._own_from = [((rank + j * world) * self.seg_len) // self.decim if (rank + j * world) else 0
-                          for j in range(len(self._segs))]
-        self._source = source
-        self._sink = sink
-        # event behind the last device-side append of each handle: kept across start() -- the previous scan's last
-        # pack kernels may still be reading the result slots this scan's first submits reuse
-        if getattr(self, "_appended", None) is None or len(self._appended) != len(self.rxs):
-            self._appended = [None] * len(self.rxs)
+        own_from = [((rank + j * world) * self.seg_len) // self.decim if (rank + j * world) else 0
+                    for j in range(len(self._segs))]
+        if not self.active():
+            self._parts = []
         # submissions: runs of up to `batch` consecutive segments of equal length
-        self._subs = sdist.group_submissions(self._segs, self.batch)
-        self._next = 0                  # next submission
-        self._done = 0                  # submissions collected
-        self._alive = {}                # submission index -> tensors (kept until collected)
-        self._parts = []
+        subs = sdist.group_submissions(self._segs, self.batch)
+        for k, sub in enumerate(subs):
+            self._jobs.append(dict(segs=[self._segs[i] for i in sub], own=[own_from[i] for i in sub], source=source, sink=sink,
+                                   on_first=on_first if k == 0 else None, on_last=on_last if k == len(subs) - 1 else None))
+        if not subs and on_first is not None:       # nothing to do for this rank: the exchange still opens and closes
+            on_first()
+        if not subs and on_last is not None:
+            on_last()
 
     def active(self) -> bool:
-        return self._done < len(self._subs)
+        return self._streams is not None and bool(self._jobs or self._flight)
+
+    def backlog(self) -> int:
+        """Submissions queued or in flight."""
+        return 0 if self._streams is None else len(self._jobs) + len(self._flight)
 
     def step(self, block: bool = True) -> bool:
-        """Submit the next segment if a slot is free (two per handle), else collect the oldest.
+        """Submit the next segment if a slot is free (``depth`` per handle), else collect the oldest.
         ``block=False``: collect only if it has finished; returns False if nothing could be done."""
         import torch
+        import time
         H = len(self.rxs)
-        if (not block and self._done < self._next and self._next - self._done >= H
-                and self.rxs[self._done % H].ready()):
+        n_fl = len(self._flight)
+        tr = getattr(self, "trace", None)           # dev aid: a list that receives (what, seconds) per host action
+        t0 = time.perf_counter() if tr is not None else 0.0
+        if (not block and n_fl >= H and self.rxs[self._done % H].ready()):
             pass                                    # results are waiting: take them before queueing more
-        elif self._next < len(self._subs) and self._next - self._done < 2 * H:
+        elif self._jobs and n_fl < self.depth * H:
             j = self._next
-            sub = self._subs[j]
+            job = self._jobs.popleft()
             st = self._streams[j % H]
             if self._appended[j % H] is not None:
                 # the result slot this submit reuses may still be being read by the sink's copy
                 st.wait_event(self._appended[j % H])
                 self._appended[j % H] = None
             with torch.cuda.stream(st):
-                xs = [self._source(*self._segs[i]) for i in sub]
+                xs = [job["source"](a, b) for a, b in job["segs"]]
                 if self.batch > 1:
                     # the library drops what a segment finds before its own range (its pre-roll)
-                    self.rxs[j % H].submit_batch(xs, [self._segs[i][0] // self.decim for i in sub],
-                                                 [self._own_from[i] if self.preroll else 0 for i in sub],
+                    self.rxs[j % H].submit_batch(xs, [a // self.decim for a, _ in job["segs"]],
+                                                 [o if self.preroll else 0 for o in job["own"]],
                                                  stream=st.cuda_stream)
                 else:
-                    self.rxs[j % H].submit(xs[0], first_sample_index=self._segs[sub[0]][0] // self.decim,
+                    self.rxs[j % H].submit(xs[0], first_sample_index=job["segs"][0][0] // self.decim,
                                            stream=st.cuda_stream)
-            self._alive[j] = xs
+            job["alive"] = xs                        # the tensors stay alive until the submission is collected
+            self._flight.append(job)
             self._next += 1
+            if tr is not None:
+                tr.append(("submit%d x%d" % (self.proto, len(xs)), time.perf_counter() - t0))
             return True
-        if self._done < self._next:
+        if n_fl:
             j = self._done
             rx = self.rxs[j % H]
             if not block and not rx.ready():
                 return False
-            own = self._own_from[self._subs[j][0]] if (self.preroll and self.batch == 1) else 0
-            if self._sink is not None:
+            job = self._flight.popleft()
+            own = job["own"][0] if (self.preroll and self.batch == 1) else 0
+            sink = job["sink"]
+            if job["on_first"] is not None:
+                job["on_first"]()
+            if sink is not None:
                 rec = rx.collect(copy=False)                    # segments of a handle complete in order
-                self._sink.append(rec, own_from=own, rx=rx)
-                if self._sink.on_gpu:
+                sink.append(rec, own_from=own, rx=rx)
+                if sink.on_gpu:
                     ev = torch.cuda.Event()
-                    ev.record(self._sink.stream)
+                    ev.record(sink.stream)
                     self._appended[j % H] = ev
             else:
                 rec = rx.collect()
                 if own:
                     rec = rec[rec["sample_index"] >= own]
                 self._parts.append(rec)
-            del self._alive[j]
+            job["alive"] = None
             self._done += 1
+            if job["on_last"] is not None:
+                job["on_last"]()
+            if tr is not None:
+                tr.append(("collect%d%s" % (self.proto, " (blocking)" if block else ""), time.perf_counter() - t0))
             return True
         return False
 

@@ -105,7 +105,7 @@ def test_cfg_layout_matches_the_header():
 int main(void) {
     printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(snout_rx_cfg), offsetof(snout_rx_cfg, device),
            offsetof(snout_rx_cfg, flags), offsetof(snout_rx_cfg, sample_format),
-           offsetof(snout_rx_cfg, batch_segments), offsetof(snout_rx_cfg, reserved), sizeof(snout_pkt));
+           offsetof(snout_rx_cfg, batch_segments), offsetof(snout_rx_cfg, reserved_cus), sizeof(snout_pkt));
     return 0;
 }
 '''
@@ -115,7 +115,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), os.path.join(d, "p.c"), "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     want = [C.sizeof(_ffi.RxCfg), _ffi.RxCfg.device.offset, _ffi.RxCfg.flags.offset,
-            _ffi.RxCfg.sample_format.offset, _ffi.RxCfg.batch_segments.offset, _ffi.RxCfg.reserved.offset,
+            _ffi.RxCfg.sample_format.offset, _ffi.RxCfg.batch_segments.offset, _ffi.RxCfg.reserved_cus.offset,
             _ffi.PKT_DTYPE.itemsize]
     assert got == want == [64, 44, 48, 52, 56, 60, 160]
 

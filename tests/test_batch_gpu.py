@@ -70,7 +70,7 @@ def test_batch_argument_checks(capture):
     with pytest.raises(SnoutError):
         SnoutRx(proto=1, n_channels=16, batch_segments=2, keep_channel_iq=True)
     with pytest.raises(SnoutError):
-        SnoutRx(proto=1, n_channels=16, batch_segments=9)
+        SnoutRx(proto=1, n_channels=16, batch_segments=65)
     plain = SnoutRx(proto=1, n_channels=16)
     with pytest.raises(SnoutError):
         plain.submit_batch([x, x], [0, 0])
@@ -81,7 +81,7 @@ def test_sharded_scan_with_batches(capture):
     n_in = capture.numel() // 2
     src = lambda a, b: capture[2 * a:2 * b]
     ref = ShardedScan(1, n_channels=16, seg_len=1 << 20).run(n_in, src)
-    for batch, handles in ((4, 1), (3, 2), (8, 1)):
+    for batch, handles in ((4, 1), (3, 2), (8, 1), (64, 1)):
         got = ShardedScan(1, n_channels=16, seg_len=1 << 20, batch=batch, handles=handles).run(n_in, src)
         assert len(got) == len(ref) > 40
         assert got.tobytes() == ref.tobytes()
@@ -151,3 +151,82 @@ def test_batch_survives_a_capacity_rerun():
         small.submit_batch(xs, firsts)
         got = small.collect()
         assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("proto,M,seg,count", [(0, 40, 40 * 4096, 31), (1, 16, 16 * 16384, 29), (0, 40, 40 * 1024, 64), (1, 16, 16 * 8192, 64)])
+def test_large_batches_equal_single_submissions(proto, M, seg, count):
+    """Up to 64 segments per submission (cfg #5 hands a rank's 48 BTLE / 20 802.15.4 segments of a step over as one):
+    the channelizer cuts every segment into ranges that fill whole rounds of workgroups, the slots (segment, channel) go
+    through every later kernel together -- the records are those of `count` single submissions, byte for byte."""
+    import torch
+    from snout_amd import synth
+    from snout_amd.rx import SnoutRx
+    ov = M * 512
+    n_in = count * (seg - ov) + ov
+    x, _ = synth.wideband_capture(proto, n_in, seed=70 + count, sigma=0.02, mean_gap=6000.0, **({} if proto == 0 else {"max_len": 30}))
+    cap = torch.from_numpy(np.ascontiguousarray(x[:n_in]).view(np.float32)).cuda()
+    segs = _segments(n_in, seg, ov)
+    assert len(segs) == count
+    D = M // 2
+    firsts = [a // D for a, _ in segs]
+    mins = [0] + [f + 100 for f in firsts[1:]]
+    xs = [cap[2 * a:2 * b] for a, b in segs]
+    one = SnoutRx(proto=proto, n_channels=M)
+    per_seg = []
+    for xk, f, m in zip(xs, firsts, mins):
+        r = one.process(xk, first_sample_index=f)
+        per_seg.append(r[r["sample_index"] >= m])
+    ref = np.concatenate(per_seg)
+    assert len(ref) > 50
+    rx = SnoutRx(proto=proto, n_channels=M, batch_segments=count)
+    rx.submit_batch(xs, firsts, mins)
+    got = rx.collect()
+    assert len(got) == len(ref) and got.tobytes() == ref.tobytes()
+
+
+def test_records_stay_on_the_device():
+    """`SNOUT_CFG_RECORDS_ON_DEVICE`: collect hands out the COUNT, nothing is downloaded; `snout_rx_pack_last_records`
+    packs the device copy (from record `skip` on) and raises a device word to the longest record; `snout_rx_collect` with a
+    buffer still downloads on request."""
+    import ctypes as C
+    import torch
+    from snout_amd import _ffi, synth
+    from snout_amd.rx import SnoutRx
+    x, _ = synth.wideband_capture(0, 40 * (1 << 15), seed=23, sigma=0.02, mean_gap=4000.0)
+    cap = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    with SnoutRx(proto=0, n_channels=40) as ref:
+        want = ref.process(cap, first_sample_index=5)
+    assert len(want) > 30
+    with SnoutRx(proto=0, n_channels=40, records_on_device=True) as rx:
+        rx.submit(cap, first_sample_index=5)
+        n = rx.collect()
+        assert isinstance(n, int) and n == len(want)
+        ptr, n_dev = rx.last_records_device()
+        assert n_dev == n and ptr
+        W = 96
+        dst = torch.zeros(n * W, dtype=torch.uint8, device="cuda")
+        longest = torch.zeros(1, dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        own = int(np.sort(want["sample_index"])[len(want) // 3])
+        assert rx.pack_last_records(dst.data_ptr(), n, W, own, st, skip=0, longest_ptr=longest.data_ptr()) == n
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy().view(np.uint8).reshape(n, W)
+        raw = want.view(np.uint8).reshape(n, 160)[:, :W].copy()
+        dropped = want["sample_index"] < own
+        assert dropped.any() and not dropped.all()
+        raw[dropped, :8] = np.frombuffer(np.uint64(1 << 62).tobytes(), dtype=np.uint8)
+        assert np.array_equal(got, raw)
+        assert int(longest.item()) == int(want["len"].max())
+        # skip: the tail of the records only; a too small destination reports the overflow
+        assert rx.pack_last_records(dst.data_ptr(), n, W, 0, st, skip=n - 7) == 7
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy()[:7 * W].reshape(7, W), want.view(np.uint8).reshape(n, 160)[n - 7:, :W])
+        assert rx.pack_last_records(dst.data_ptr(), 3, W, 0, st, skip=n - 7) == 3
+        # the copying collect still delivers records (downloaded on request)
+        rx.submit(cap, first_sample_index=5)
+        out = np.zeros(n + 8, dtype=_ffi.PKT_DTYPE)
+        n_out = C.c_uint64(0)
+        _ffi.check(rx._lib.snout_rx_collect(rx._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n_out)))
+        assert n_out.value == n and out[:n].tobytes() == want.tobytes()
+        # and the synchronous entry point is unchanged
+        assert rx.process(cap, first_sample_index=5).tobytes() == want.tobytes()

@@ -67,6 +67,7 @@ def test_default_run_carries_every_workload():
         assert w["parity_in_run"]["equal"] is True and w["parity_in_run"]["records"] > 100
     assert d["parity_in_run"]["equal"] is True and d["parity_in_run"]["samples"] == 40 * (1 << 21)
     assert ow["cfg5"]["segments_per_gpu"] == 48 + 20 and ow["cfg5"]["decoded_crc_ok"] >= ow["cfg5"]["min_expected_crc_ok"] > 0
+    assert ow["cfg5"]["segments_per_submission"] == {"btle": 48, "zigbee": 20}
 
 
 def test_two_ranks_run_cfg5_over_gloo():
@@ -156,7 +157,7 @@ def test_cfg5_exchange_runs_on_rccl_at_world_one():
     env = dict(os.environ, SNOUT_BENCH_NCCL1="1")
     d = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1", env=env)
     c = d["config"]
-    assert c["collective"] == "RCCL all_gather_into_tensor" and c["ranks_in_collective"] == 1 and c["device_of_rank0"] == 0
+    assert c["collective"].startswith("RCCL all_gather (32-B headers) + gather to rank 0") and c["ranks_in_collective"] == 1 and c["device_of_rank0"] == 0
     assert "RCCL" in c["sharding"] and c["decoded_crc_ok"] >= c["min_expected_crc_ok"] > 0
     plain = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1")
     assert plain["config"]["collective"].startswith("none") and plain["config"]["decoded_crc_ok"] == c["decoded_crc_ok"]
@@ -169,6 +170,21 @@ def test_headline_exchange_runs_on_rccl_at_world_one():
     env = dict(os.environ, SNOUT_BENCH_NCCL1="1")
     d = _bench("--workload", "cfg3", "--steps", "3", "--warmup", "1", "--samples", "4e7", "--no-cpu", env=env)
     c = d["config"]
-    assert c["collective"] == "RCCL all_gather_into_tensor" and c["ranks_in_collective"] == 1 and "nccl" in c["sharding"]
+    assert c["collective"].startswith("RCCL all_gather (32-B headers) + gather to rank 0") and c["ranks_in_collective"] == 1 and "nccl" in c["sharding"]
     assert c["records_on_rank0_last_step"] == c["packets_per_gpu"] > 0
     assert c["decoded_crc_ok_per_gpu"] >= c["min_expected_crc_ok_per_gpu"] > 0
+
+
+def test_rank0_load_of_eight_ranks_is_rehearsed_at_world_one():
+    """`SNOUT_BENCH_FAKE_WORLD=8` on the RCCL backend at world size 1 -- after the real exchange rank 0
+    holds EIGHT blocks of records (its own, sample_index shifted per block), sorts / de-duplicates them on the GPU and
+    downloads them inside the timed region, as rank 0 of an 8-GPU run will.  Both bench paths: cfg #5 (device dedup) and
+    the headline workload with its per-step gather."""
+    env = dict(os.environ, SNOUT_BENCH_NCCL1="1", SNOUT_BENCH_FAKE_WORLD="8")
+    plain = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1", env=dict(os.environ, SNOUT_BENCH_NCCL1="1"))
+    d = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1", env=env)
+    c, p = d["config"], plain["config"]
+    assert c["fake_world"]["blocks_on_rank0"] == 8 and c["records_on_rank0"] == 8 * p["records_on_rank0"]
+    assert c["decoded_crc_ok"] == 8 * p["decoded_crc_ok"] and c["collective"].startswith("RCCL")
+    h = _bench("--workload", "cfg3", "--steps", "3", "--warmup", "1", "--samples", "4e7", "--no-cpu", env=env)
+    assert h["config"]["fake_world"] == 8 and h["config"]["records_on_rank0_last_step"] == 8 * h["config"]["packets_per_gpu"] > 0

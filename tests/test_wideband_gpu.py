@@ -79,16 +79,34 @@ print("equal")
 @pytest.mark.parametrize("impl,M,proto,block", [("valu", 40, 0, False), ("valu", 16, 1, False), ("spec12", 40, 0, False),
                                                  ("mfma", 40, 0, True)])
 def test_the_kept_ab_partners_of_the_channelizer_are_bit_exact_too(impl, M, proto, block):
-    """`SNOUT_PFB_IMPL` (read when a handle is created) selects the kernels kept beside the shipped `pfb_spec`: round 2's
+    """In `libsnout_rx_ab.so` (`make -C snout_amd/csrc ab`: the product sources plus `pfb.hip` and `pfb_mfma.hip`)
+    `SNOUT_PFB_IMPL` (read when a handle is created) selects the kernels kept beside the shipped `pfb_spec`: round 2's
     `pfb_channelize` (valu), the 12-wave layout (spec12) -- both the plain fmaf chain of `oracle_pfb` -- and the matrix-pipe
     FIR (mfma) = `oracle_pfb_block_order` (banded-Toeplitz blocks of `v_mfma_f32_16x16x4_f32`; the snippet's input carries a
     NaN, which is where the two orders differ), bit for bit."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SNOUT_PFB_IMPL=impl)
+    env = dict(os.environ, SNOUT_PFB_IMPL=impl, SNOUT_RX_LIB=os.path.join(root, "snout_amd", "lib", "libsnout_rx_ab.so"))
     r = subprocess.run([sys.executable, "-c", _IMPL_SNIPPET % dict(root=root, M=M, proto=proto, block=block)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("equal"), r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("impl", ["valu", "mfma", "VALU", "pfb"])
+def test_the_product_library_carries_one_channelizer(impl):
+    """The product library refuses to pretend: any `SNOUT_PFB_IMPL` other than `spec` -- an A/B kernel it does not carry, or
+    a typo -- fails the creation of a wideband handle instead of silently timing the shipped kernel under another name;
+    the A/B library refuses unknown names the same way."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom snout_amd.rx import SnoutRx\nfrom snout_amd._ffi import SnoutError\n"
+            "try:\n    SnoutRx(proto=0, n_channels=40)\n    print('created')\nexcept SnoutError as e:\n    print('refused', e.code)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, SNOUT_PFB_IMPL=impl))
+    assert r.returncode == 0 and r.stdout.strip() == "refused -1", r.stdout + r.stderr[-2000:]
+    if impl in ("VALU", "pfb"):
+        env = dict(os.environ, SNOUT_PFB_IMPL=impl, SNOUT_RX_LIB=os.path.join(root, "snout_amd", "lib", "libsnout_rx_ab.so"))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and r.stdout.strip() == "refused -1", r.stdout + r.stderr[-2000:]
 
 
 def test_channelizer_shorter_than_prototype():
