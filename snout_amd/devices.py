@@ -18,13 +18,26 @@ UUID128_KEY = "Incomplete List of 128-bit Service Class UUIDs"
 COLUMNS = ["MAC", "Last Seen", "#", "Up", "Vendor", "Model", "OS", "Info"]
 
 
+_AGO_UNITS = (60.0, 60.0, 24.0, 7.0, 365.0 / 7.0 / 12.0, 12.0)
+_AGO_TEXT = ("just now", "%s seconds ago", "1 minute ago", "%s minutes ago", "1 hour ago", "%s hours ago", "1 day ago",
+             "%s days ago", "1 week ago", "%s weeks ago", "1 month ago", "%s months ago", "1 year ago", "%s years ago")
+
+
 def _ago(seconds: float) -> str:
-    s = int(max(0.0, seconds))
-    if s < 60:
-        return "just now" if s < 10 else f"{s} seconds ago"
-    if s < 3600:
-        return f"{s // 60} minute{'s' if s >= 120 else ''} ago"
-    return f"{s // 3600} hour{'s' if s >= 7200 else ''} ago"
+    """English text of the `timeago` package the reference formats its times with (device.py:139-143, :279): the
+    difference is divided through 60 s, 60 min, 24 h, 7 d, weeks per month, 12 months while it reaches the next unit;
+    "just now" up to 9 s, the singular form at exactly one unit.  Pinned by tests/golden/devices.json."""
+    diff = max(0.0, float(seconds))
+    i = 0
+    while i < len(_AGO_UNITS) and diff >= _AGO_UNITS[i]:
+        diff /= _AGO_UNITS[i]
+        i += 1
+    n = int(diff)
+    i *= 2
+    if n > (9 if i == 0 else 1):
+        i += 1
+    t = _AGO_TEXT[i]
+    return t % n if "%s" in t else t
 
 
 @dataclass
@@ -56,10 +69,26 @@ class DeviceEntry:
 
     @property
     def uptime_nice(self) -> str:
+        """The "Up" column exactly as the reference prints it (device.py:155-167) -- including its arithmetic above one
+        hour, which subtracts the HOUR COUNT (not the hours' seconds) before taking minutes and seconds: 3725 s prints as
+        ``01:62:04``, one hour sharp as ``60:00``.  A drop-in prints what the reference prints; :attr:`uptime_hms` is the
+        same duration in conventional clock form."""
         up = self.uptime
         if up < 0:
             return "-"
-        if up > 3600:
+        nice = "%02d:%02d" % (up / 60, up % 60)
+        if up > 60 * 60:
+            hours = int(up / (60 * 60))
+            nice = "%02d:%02d:%02d" % (up / (60 * 60), (up - hours) / 60, (up - hours) % 60)
+        return nice
+
+    @property
+    def uptime_hms(self) -> str:
+        """hh:mm:ss (mm:ss below one hour) of :attr:`uptime`; not a column of the reference's table."""
+        up = self.uptime
+        if up < 0:
+            return "-"
+        if up >= 3600:
             return "%02d:%02d:%02d" % (up // 3600, (up % 3600) // 60, up % 60)
         return "%02d:%02d" % (up // 60, up % 60)
 

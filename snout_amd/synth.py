@@ -164,6 +164,27 @@ def btle_capture(n_samples: int, channel: int = 37, seed: int = 1, mean_gap: flo
     return x, truth
 
 
+def btle_capture_of(pdus: Sequence[bytes], spacing: int = 20000, channel: int = 37, seed: int = 1, sigma: float = 0.02,
+                    first: int = 2048, fs: float = 4e6, cfo_max_hz: float = 20e3) -> Tuple[np.ndarray, List[TruthPacket]]:
+    """A capture that carries exactly the given advertising PDUs, one every ``spacing`` samples from sample ``first``
+    (small random CFO and phase per packet, AWGN everywhere): loopback input for tests that care about WHAT is sent."""
+    rng = np.random.default_rng(seed)
+    n_samples = first + spacing * len(pdus) + 4096
+    x = np.zeros(n_samples, dtype=np.complex64)
+    truth: List[TruthPacket] = []
+    pad = 4
+    for k, pdu in enumerate(pdus):
+        wave = gfsk_modulate(btle_air_bits(pdu, channel), pad_symbols=pad)
+        assert wave.size + 64 < spacing
+        pos = first + k * spacing
+        cfo = rng.uniform(-cfo_max_hz, cfo_max_hz)
+        rot = np.exp(1j * (2 * math.pi * cfo / fs * np.arange(wave.size) + rng.uniform(0, 2 * math.pi))).astype(np.complex64)
+        x[pos:pos + wave.size] += (wave * rot).astype(np.complex64)
+        truth.append(TruthPacket(0, channel, pos + (pad + 8) * BTLE_SPS, pdu, {"cfo": cfo}))
+    x += (sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))).astype(np.complex64)
+    return x, truth
+
+
 def to_interleaved(x: np.ndarray) -> np.ndarray:
     """complex64[n] -> float32[2n] view (re, im interleaved), the on-disk/ABI layout."""
     x = np.ascontiguousarray(x, dtype=np.complex64)

@@ -64,6 +64,28 @@ def test_pcap_roundtrip(tmp_path):
     assert abs(got[1][0] - 1567108497.999999) < 1e-6
 
 
+def test_pcap_bytes_are_the_libpcap_file_format(tmp_path):
+    """Byte-level known answer, independent of `read_pcap`: what `scapy.wrpcap(filename, pkt.payload, append=True)`
+    (snout/util/zigbee.py:202) puts on disk for 802.15.4 frames is the classic libpcap file -- global header: magic
+    a1b2c3d4 in the writer's byte order, version 2.4, thiszone 0, sigfigs 0, snaplen 65535, link type 195
+    (LINKTYPE_IEEE802_15_4_WITHFCS); per frame: seconds, microseconds, captured length, wire length, then the bytes --
+    and `file(1)` recognises it."""
+    import subprocess
+    p = str(tmp_path / "k.pcap")
+    mpdu = bytes.fromhex("03083affffffff07aabb")
+    assert formats.write_pcap(p, [(1567108496.25, mpdu)]) == 1
+    raw = open(p, "rb").read()
+    assert raw[:24] == bytes.fromhex("d4c3b2a1" "0200" "0400" "00000000" "00000000" "ffff0000" "c3000000")
+    assert raw[24:40] == (1567108496).to_bytes(4, "little") + (250000).to_bytes(4, "little") + (10).to_bytes(4, "little") * 2
+    assert raw[40:] == mpdu and len(raw) == 50
+    # appending keeps ONE global header
+    assert formats.write_pcap(p, [(1567108497.0, b"\x01\x02")], append=True) == 1
+    raw2 = open(p, "rb").read()
+    assert raw2[:50] == raw and raw2.count(bytes.fromhex("d4c3b2a1")) == 1 and len(raw2) == 50 + 16 + 2
+    out = subprocess.run(["file", "-b", p], capture_output=True, text=True).stdout.lower()
+    assert "pcap capture file" in out and "version 2.4" in out and ("802.15.4" in out or "195" in out), out
+
+
 def test_btle_scan_stop_rules_without_gpu(monkeypatch):
     """check_stop semantics of snout/util/btle.py:111-122 on a stubbed line source."""
     from snout_amd.scan import BtleScan

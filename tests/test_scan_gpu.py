@@ -95,3 +95,30 @@ def test_cli_sharded_two_ranks_over_gloo(tmp_path):
     f1 = sorted(ln.split()[-1] for ln in one.stdout.decode().splitlines() if " Ch" in ln)
     f2 = sorted(ln.split()[-1] for ln in two.stdout.decode().splitlines() if " Ch" in ln)
     assert len(f1) >= 0.8 * len(truth) and f1 == f2
+
+
+def test_gpu_scan_feeds_the_reference_device_table():
+    """IQ -> `BtleScan` on the GPU -> btle_rx lines -> AdvData dissection -> device table, end to end against the
+    REFERENCE's own classes: tests/golden/devices.json holds, for the "capture" scenario, the lines the CPU oracle prints
+    for a capture of known advertising PDUs and the table rows the imported reference (snout/core/message.py:205-237,
+    snout/core/device.py:131-295, snout/util/btle.py:202-240) makes of them (tests/golden/make_golden_devices.py).  The
+    GPU scan of the same capture must print the same lines and fill the same table."""
+    from snout_amd import devices
+    from snout_amd.scan import ArraySource, BtleScan
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "devices.json")))["scenarios"]["capture"]
+    cap = gold["capture"]
+    pdus = [synth.btle_adv_pdu(0, bytes.fromhex(mac), bytes.fromhex(adv), txadd=1) for mac, adv in cap["packets"]]
+    x, _ = synth.btle_capture_of(pdus, spacing=cap["spacing"], seed=cap["seed"], sigma=cap["sigma"])
+    scan = BtleScan(channels=[37], source=ArraySource({37: x}), timeout=None, t0_epoch=cap["t0"])
+    lines = [ln.decode() for ln in scan.lines(37)]
+    assert lines == gold["lines"]
+    scan2 = BtleScan(channels=[37], source=ArraySource({37: x}), timeout=None, t0_epoch=cap["t0"])
+    msgs = scan2.run()
+    assert len(msgs) == len(pdus) == sum(gold["accepted"])
+    table = devices.DeviceTable().extend(msgs)
+    assert table.rows(now=gold["now"]) == gold["rows"]
+    # the dissected payload of a decoded packet is what the reference's dissector returns for its AdvData (advdata.json pins
+    # the dissector itself): Apple Nearby, action 3, iOS 12 hint, Wi-Fi on
+    first = msgs[0].payload
+    assert first["company_id"] == 0x004C and first["manufacturer-specific"][0]["Action Code Text"] == "Locked Screen"
+    assert first["manufacturer-specific"][0]["iOS Version Hint"] == "12" and first["manufacturer-specific"][0]["Wi-Fi"] == "On"
