@@ -15,7 +15,7 @@ import sys
 import click
 
 from . import synth
-from .scan import ArraySource, BtleScan, FileSource, WidebandSource, ZigbeeScan
+from .scan import ArraySource, BtleScan, FileSource, StreamSource, WidebandSource, ZigbeeScan
 
 DEFAULTS = {"btle": dict(channels=(0, 39), default=37, timeout=10),      # snout/util/__init__.py:4-17
             "zigbee": dict(channels=(11, 26), default=11, timeout=10)}
@@ -94,12 +94,34 @@ def _source(proto, iq, synthetic, channels, seconds, fmt="cf32", wideband=False,
             x = synth.quantize(x, FORMATS[fmt]).reshape(-1, 2)
         return WidebandSource(x, pid, FORMATS[fmt], segment=segment, sharded=sharded, batch=batch)
     if iq:
-        return FileSource(iq, FORMATS[fmt])
+        return _file_or_stream(iq, FORMATS[fmt])
     if not synthetic:
         raise click.UsageError("give --iq FILE or --synthetic (no live SDR in this build)")
     n = int(seconds * 4e6)
     gen = synth.btle_capture if proto == "btle" else synth.zigbee_capture
     return ArraySource({ch: gen(n, channel=ch, seed=ch)[0] for ch in channels})
+
+
+def _file_or_stream(iq: str, fmt: int):
+    """``-`` (stdin), a FIFO or a character device is a live stream (`hackrf_transfer -r - | ... --iq -`): read once, in
+    overlapping segments, -t by the wall clock; a regular file is a capture: -t is capture time."""
+    import os
+    import stat
+    if iq == "-":
+        return StreamSource("-", fmt)
+    mode = os.stat(iq).st_mode
+    if stat.S_ISFIFO(mode) or stat.S_ISCHR(mode) or stat.S_ISSOCK(mode):
+        return StreamSource(iq, fmt)
+    return FileSource(iq, fmt)
+
+
+def _iq_path(ctx, param, value):
+    if value is None or value == "-":
+        return value
+    import os
+    if not os.path.exists(value):
+        raise click.BadParameter(f"{value!r} does not exist")
+    return value
 
 
 def _scan_options(f):
@@ -120,7 +142,8 @@ def _scan_options(f):
         click.option("--batch", type=click.IntRange(1, 8), default=4,
                      help="wideband: segments handed to the GPU as one submission"),
         click.option("-f", "--filename", default=None, help="dump file"),
-        click.option("--iq", type=click.Path(exists=True), default=None, help="capture file"),
+        click.option("--iq", callback=_iq_path, default=None,
+                     help="capture file; '-' (stdin) or a FIFO: a live stream, read in overlapping segments, -t by the wall clock"),
         click.option("--format", "fmt", type=click.Choice(sorted(FORMATS)), default="cf32",
                      help="sample format of --iq: cf32, sc8 (hackrf_transfer int8), sc16"),
         click.option("--synthetic", is_flag=True, help="generate a synthetic capture"),
@@ -189,15 +212,16 @@ def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, 
 @click.option("-g", "gain", type=int, default=6, help="accepted for btle_rx compatibility")
 @click.option("-a", "access", default="8e89bed6")
 @click.option("-k", "crcinit", default="555555")
-@click.option("--iq", type=click.Path(exists=True), required=True)
+@click.option("--iq", callback=_iq_path, required=True, help="capture file, or '-' / a FIFO for a live stream")
 @click.option("--format", "fmt", type=click.Choice(sorted(FORMATS)), default="cf32")
 def btle_rx(channel, gain, access, crcinit, iq, fmt):
-    """Drop-in for the `btle_rx` child: same argv (snout/util/btle.py:63-68), same stdout lines."""
-    scan = BtleScan(channels=[channel], source=FileSource(iq, FORMATS[fmt]), timeout=None,
+    """Drop-in for the `btle_rx` child: same argv (snout/util/btle.py:63-68), same stdout lines.
+    `hackrf_transfer -r - ... | btle_rx -c 37 --format sc8 --iq -` receives a live stream: lines appear segment by segment."""
+    scan = BtleScan(channels=[channel], source=_file_or_stream(iq, FORMATS[fmt]), timeout=None,
                     access_addr=int(access, 16), crc_init=int(crcinit, 16))
     for line in scan.lines(channel):
         sys.stdout.write(line.decode())
-    sys.stdout.flush()
+        sys.stdout.flush()
 
 
 def btle_rx_main():

@@ -6,7 +6,8 @@ The scan loop semantics are the reference's: channels are visited in order; each
 through ``handle_packet`` (which applies the same accept rule as BtleMessage.fromraw, appends to
 ``packets``, writes the dump file and emits ``btle.packet-received``); ``check_stop`` ends a
 channel when ``packet_threshold`` packets were seen or ``timeout`` seconds elapsed.  With a
-recorded/synthetic capture "elapsed" is capture time (sample_index / fs), not wall-clock.
+recorded/synthetic capture "elapsed" is capture time (sample_index / fs); with a live stream
+(``StreamSource``: stdin, a FIFO) it is the wall clock, as in the reference.
 """
 from __future__ import annotations
 
@@ -53,6 +54,112 @@ class FileSource(IqSource):
             return np.memmap(self.path, dtype=np.complex64, mode="r")
         a = np.memmap(self.path, dtype=np.int8 if self.sample_format == 1 else np.int16, mode="r")
         return a[:a.size // 2 * 2].reshape(-1, 2)
+
+
+class StreamSource(IqSource):
+    """A LIVE sample stream: stdin (``"-"``), a FIFO, a socket file -- anything that is read once, front to back, e.g.
+    ``hackrf_transfer -r - | btle_rx -c 37 --format sc8 --iq -``.  This is how the reference's receivers get their samples
+    (upstream btle_rx: a ring buffer of the radio's transfers processed half at a time with a tail of the longest packet,
+    SURVEY Appendix A.1; the scan around it runs by the wall clock, snout/util/btle.py:111-122, snout/core/radio.py:399-443).
+
+    ``segments()`` cuts the stream into segments of ``segment`` samples that overlap by the longest packet (802.15.4: plus the
+    pre-roll of the DC filter, as the sharded scan does), uploads each as it completes and keeps two in flight on the GPU
+    (submit / collect); it yields one record array per segment, in stream order, duplicates of the overlaps removed --
+    the records of the same samples read from a file.  A scan over a StreamSource measures ``timeout`` by the wall clock
+    (``live = True``), as the reference does; ``sample_index`` stays the position in the stream."""
+
+    live = True
+
+    def __init__(self, stream, sample_format: int = 0, segment: int = 1 << 22):
+        self.sample_format = int(sample_format)
+        self.segment = int(segment)
+        if stream == "-":
+            import sys
+            stream = sys.stdin.buffer
+        elif isinstance(stream, (str, bytes, os.PathLike)):
+            stream = open(stream, "rb", buffering=0)
+        self.stream = stream
+        self.samples_read = 0
+
+    def read(self, channel: int) -> np.ndarray:
+        raise TypeError("a live stream is read once, in segments: use segments()")
+
+    def _read_exact(self, nbytes: int) -> bytes:
+        """Up to nbytes from the stream; shorter only at its end (a pipe hands over what the writer has flushed)."""
+        parts, have = [], 0
+        while have < nbytes:
+            b = self.stream.read(nbytes - have)
+            if not b:
+                break
+            parts.append(b)
+            have += len(b)
+        return b"".join(parts)
+
+    def segments(self, proto: int, channel: int, device: int = -1, should_stop: Optional[Callable[[], bool]] = None, **rx_kw):
+        import collections
+        import torch
+        bps = {0: 8, 1: 2, 2: 4}[self.sample_format]
+        np_dt = {0: np.float32, 1: np.int8, 2: np.int16}[self.sample_format]
+        zb = proto == _ffi.PROTO_ZIGBEE
+        overlap = ZIGBEE_OVERLAP if zb else BTLE_OVERLAP
+        preroll = 4 * 6250 if zb else 0            # sharded.ZIGBEE_PREROLL_CH: the DC estimate restarts with every segment
+        seg = max(self.segment, 4 * (overlap + preroll))
+        dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+        rx = SnoutRx(proto=proto, channel=channel, device=device, sample_format=self.sample_format, **rx_kw)
+        flight = collections.deque()                # (tensor kept alive, own_from)
+        carry = b""
+        first = 0                                   # stream position of the first sample of the next segment
+        seen_until = -1
+        recent = []
+
+        def fresh(rec, own_from):
+            """Drop what the segment before has reported (BTLE: by position; 802.15.4: same bytes within the tolerance
+            the sharded scan uses) and what this segment found in its pre-roll."""
+            nonlocal seen_until, recent
+            keep = []
+            now = []
+            for i, p in enumerate(rec):
+                si = int(p["sample_index"])
+                if si < own_from:
+                    continue
+                if zb:
+                    body = bytes(p["bytes"][:p["len"]])
+                    if any(abs(si - s0) <= 8 * 64 + 8 and body == b0 for s0, b0 in recent):
+                        continue
+                    now.append((si, body))
+                else:
+                    if si <= seen_until:
+                        continue
+                    seen_until = si
+                keep.append(i)
+            if zb:
+                recent = now
+            return rec[keep]
+        try:
+            eof = False
+            while not eof:
+                data = self._read_exact(seg * bps - len(carry))
+                buf = carry + data
+                n = len(buf) // bps
+                eof = len(data) < seg * bps - len(carry)
+                self.samples_read += len(data) // bps
+                if n and (len(data) or not first):
+                    t = torch.frombuffer(bytearray(buf[:n * bps]), dtype={0: torch.float32, 1: torch.int8, 2: torch.int16}[self.sample_format]).to(dev)
+                    rx.submit(t, first_sample_index=first)
+                    flight.append((t, first + preroll if first else 0))
+                    keep = overlap + preroll
+                    if n > keep:
+                        carry = buf[(n - keep) * bps:n * bps]
+                        first += n - keep
+                    else:
+                        carry, eof = b"", True
+                while len(flight) > (0 if eof else 1):
+                    _, own = flight.popleft()
+                    yield fresh(rx.collect(), own)
+                    if should_stop is not None and should_stop():
+                        return
+        finally:
+            rx.close()
 
 
 class ArraySource(IqSource):
@@ -204,6 +311,18 @@ class BtleScan:
                 yield btle_format_line(p, BTLE_FS, self.t0_epoch, self._pkt_no, self.access_addr)
                 self._pkt_no += 1
             return
+        if hasattr(self.source, "segments"):         # a live stream: segments as they arrive, timeout by the wall clock
+            t_start = time.time()
+            for rec in self.source.segments(_ffi.PROTO_BTLE, channel, self.device, access_addr=self.access_addr,
+                                            crc_init=self.crc_init):
+                for p in rec:
+                    self._elapsed = time.time() - t_start
+                    yield btle_format_line(p, BTLE_FS, self.t0_epoch, self._pkt_no, self.access_addr)
+                    self._pkt_no += 1
+                self._elapsed = time.time() - t_start
+                if self.timeout and self._elapsed >= self.timeout:
+                    return
+            return
         x = self.source.read(channel)
         seen_until = -1
         for rec in _pipelined_segments(_ffi.PROTO_BTLE, channel, x, getattr(self.source, "sample_format", 0),
@@ -278,6 +397,16 @@ class ZigbeeScan:
             for p in self.source.records(channel):
                 self._elapsed = int(p["sample_index"]) / ZIGBEE_FS
                 yield p
+            return
+        if hasattr(self.source, "segments"):         # a live stream: segments as they arrive, timeout by the wall clock
+            t_start = time.time()
+            for rec in self.source.segments(_ffi.PROTO_ZIGBEE, channel, self.device):
+                for p in rec:
+                    self._elapsed = time.time() - t_start
+                    yield p
+                self._elapsed = time.time() - t_start
+                if self.timeout and self._elapsed >= self.timeout:
+                    return
             return
         x = self.source.read(channel)
         recent = []                     # (sample_index, bytes) of the frames of the segment before

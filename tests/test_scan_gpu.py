@@ -122,3 +122,90 @@ def test_gpu_scan_feeds_the_reference_device_table():
     first = msgs[0].payload
     assert first["company_id"] == 0x004C and first["manufacturer-specific"][0]["Action Code Text"] == "Locked Screen"
     assert first["manufacturer-specific"][0]["iOS Version Hint"] == "12" and first["manufacturer-specific"][0]["Wi-Fi"] == "On"
+
+
+def _feed(path, data: bytes, chunk: int, delay: float):
+    """Writer side of a live stream: the capture in paced chunks, as a radio's transfers arrive."""
+    import time
+    with open(path, "wb", buffering=0) as f:
+        for lo in range(0, len(data), chunk):
+            f.write(data[lo:lo + chunk])
+            time.sleep(delay)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_live_stream_gives_the_records_of_the_file(tmp_path, fmt):
+    """Row a11's live half: `StreamSource` reads a FIFO fed in paced chunks (odd sizes: segment boundaries fall anywhere),
+    cuts overlapping segments into submit / collect and must print exactly the lines of the same samples read from a
+    file -- cf32 and the HackRF's int8 pairs; the wall clock, not capture time, is what `timeout` measures."""
+    import threading
+    import time
+    from snout_amd.scan import BtleScan, FileSource, StreamSource
+    x, truth = synth.btle_capture(3 * (1 << 20) + 12345, channel=37, seed=77, mean_gap=6000.0)
+    if fmt == 1:
+        data = synth.quantize(x, 1).tobytes()
+    else:
+        data = x.tobytes()
+    f = tmp_path / "cap.bin"
+    f.write_bytes(data)
+    want = list(BtleScan(channels=[37], source=FileSource(str(f), fmt), timeout=None, t0_epoch=100.0).lines(37))
+    assert len(want) >= len(truth) > 300
+    fifo = str(tmp_path / "iq.fifo")
+    os.mkfifo(fifo)
+    th = threading.Thread(target=_feed, args=(fifo, data, 999983, 0.002))
+    th.start()
+    src = StreamSource(fifo, fmt, segment=1 << 19)
+    got = list(BtleScan(channels=[37], source=src, timeout=None, t0_epoch=100.0).lines(37))
+    th.join()
+    assert src.samples_read == len(x) and got == want
+    # wall-clock timeout: a slow stream is left after `timeout` seconds although the capture time is far shorter
+    os.unlink(fifo)
+    os.mkfifo(fifo)
+    slow = data[:(len(data) // 6) // 8 * 8]
+    bps = 8 if fmt == 0 else 2
+    th = threading.Thread(target=_feed, args=(fifo, slow, (1 << 15) * bps, 0.2))       # 2^15 samples every 0.2 s
+    th.start()
+    t0 = time.time()
+    scan = BtleScan(channels=[37], source=StreamSource(fifo, fmt, segment=1 << 17), timeout=1.0, t0_epoch=100.0)
+    try:
+        msgs = scan.run()
+        took = time.time() - t0
+    finally:
+        # unblock the writer: read the rest of the FIFO away
+        with open(fifo, "rb") as rest:
+            while rest.read(1 << 20):
+                pass
+        th.join()
+    # 2^17-sample segments arrive every 0.8 s and the first is collected once the second is on its way: the scan ends with
+    # the first records after 1 s, long before the stream does (16 chunks = 3.2 s) and with a fraction of its packets
+    assert 0 < len(msgs) < len(want) // 8 and 1.0 <= took < 3.0
+
+
+def test_live_stream_zigbee_and_the_cli_on_stdin(tmp_path):
+    """802.15.4 over a live stream (segments restart the DC filter: every later segment starts a pre-roll early and leaves
+    what it finds there to the segment before), and the drop-in child on a pipe: `... | btle_rx -c 37 --iq -`."""
+    import threading
+    from snout_amd.scan import StreamSource, ZigbeeScan
+    x, truth = synth.zigbee_capture(1 << 21, channel=15, seed=78, mean_gap=20000.0)
+    fifo = str(tmp_path / "zb.fifo")
+    os.mkfifo(fifo)
+    th = threading.Thread(target=_feed, args=(fifo, x.tobytes(), 1 << 20, 0.001))
+    th.start()
+    msgs = ZigbeeScan(channels=[15], source=StreamSource(fifo, 0, segment=1 << 19), timeout=None).run()
+    th.join()
+    sent = [t.payload for t in truth]
+    found = [m.mpdu for m in msgs]
+    assert len(truth) > 20 and sum(p in found for p in sent) >= len(sent) - 1
+    assert len(found) == len(set((m.timestamp, m.mpdu) for m in msgs))              # nothing reported twice
+    # the child process on stdin
+    xb, tb = synth.btle_capture(1 << 20, channel=37, seed=79, mean_gap=8000.0)
+    f = tmp_path / "b.cf32"
+    xb.tofile(f)
+    exe = [sys.executable, os.path.join(ROOT, "bin", "btle_rx"), "-c", "37", "-g", "6", "-a", "8e89bed6", "-k", "555555"]
+    ref = subprocess.run(exe + ["--iq", str(f)], capture_output=True, timeout=300)
+    piped = subprocess.run(exe + ["--iq", "-"], input=xb.tobytes(), capture_output=True, timeout=300)
+    assert ref.returncode == 0 and piped.returncode == 0, piped.stderr.decode()[-2000:]
+
+    def strip_time(out):        # the epoch of a line is the process's start time + sample_index / fs
+        return [ln.split(b" ", 1)[1] for ln in out.splitlines()]
+    assert len(strip_time(ref.stdout)) >= len(tb) > 50 and strip_time(piped.stdout) == strip_time(ref.stdout)
