@@ -195,7 +195,10 @@ def cpu_baseline(x_dev, workload: str, n_sample: int):
 # ------------------------------------------------------------------------------------------------
 # parity in the same run: the HIP path and the oracle on the same prefix of the capture
 # ------------------------------------------------------------------------------------------------
-PARITY_FIELDS = ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags")
+PARITY_FIELDS = ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags", "aux")
+# workloads whose WHOLE capture the oracle decodes in seconds to tens of seconds on the GPU box's host cores (as one
+# segment: all threads inside the channelizer, then one per bin; cfg2: the scalar loop, ~17 s per 1e9 samples)
+PARITY_FULL = ("cfg2", "cfg3", "cfg4")
 
 
 def oracle_records(x_dev, workload: str, n_sample: int):
@@ -216,15 +219,20 @@ def oracle_records(x_dev, workload: str, n_sample: int):
         oracle_py.set_threads(1)
 
 
-def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=None):
+def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=None, got=None):
     """What the reference's consumer keeps are the decoded records (snout/core/message.py:226 keeps the CRC0
-    lines): the GPU's record set on the prefix must EQUAL the oracle's -- every field and every byte."""
+    lines): the GPU's record set on the first n_sample samples (the whole capture for PARITY_FULL workloads) must EQUAL
+    the oracle's -- every field and every byte.  ``got``: the HIP path's records of exactly those samples, if the
+    caller has them already."""
     from snout_amd.rx import SnoutRx
     proto, n_ch, channel = WORKLOADS[workload][:3]
+    t0 = time.perf_counter()
     if want is None:
         want = oracle_records(x_dev, workload, n_sample)
-    with SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt) as rx:
-        got = rx.process(x_dev[:2 * n_sample]).copy()
+    t_oracle = time.perf_counter() - t0
+    if got is None:
+        with SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt) as rx:
+            got = rx.process(x_dev[:2 * n_sample]).copy()
 
     def canon(r):
         return r[np.lexsort((r["len"], r["sample_index"], r["channel"]))]
@@ -233,8 +241,8 @@ def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=No
         a, b = canon(got), canon(want)
         equal = all(np.array_equal(a[f], b[f]) for f in PARITY_FIELDS) and np.array_equal(a["bytes"], b["bytes"])
     assert equal, f"{workload}: the GPU's records on the first {n_sample} samples differ from the oracle's ({len(got)} vs {len(want)})"
-    return {"workload": workload, "samples": int(n_sample), "records": int(len(want)),
-            "crc_ok_records": int(want["crc_ok"].sum()), "equal": True,
+    return {"workload": workload, "samples": int(n_sample), "whole_capture": bool(n_sample * 2 == x_dev.numel()),
+            "records": int(len(want)), "crc_ok_records": int(want["crc_ok"].sum()), "equal": True, "oracle_s": round(t_oracle, 2),
             "compared": "every record field and byte, set equality after sorting by (channel, sample_index), against the CPU oracle"}
 
 
@@ -381,7 +389,9 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         res["reserved_cus"] = rcus
     rx.close()
     if parity_samples:
-        res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt)
+        # the whole capture where the oracle finishes it in seconds (first_sample_index 0: rank 0's own capture)
+        full = parity_samples >= n and rank == 0
+        res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt, got=local if full else None)
     if keep_capture:
         return res, x
     del x
@@ -617,6 +627,9 @@ def main():
     ap.add_argument("--cpu-samples", type=float, default=0,
                     help="samples of the CPU baseline legs (default: ~10 s of oracle time per leg)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--parity", choices=["full", "prefix"], default="full",
+                    help="parity_in_run of cfg2 / cfg3 / cfg4: the whole capture against the oracle (default; tens of seconds of "
+                         "host time outside the timed region) or only the CPU leg's prefix")
     ap.add_argument("--no-others", action="store_true", help="N = 1: skip the other_workloads block")
     ap.add_argument("--sync", action="store_true",
                     help="one segment at a time (no submit/collect pipelining); for profiling")
@@ -714,16 +727,21 @@ def main():
             if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
                 ns = int(min(args.cpu_samples or CPU_SAMPLES[headline], n))
                 out["cpu_baseline"], cpu_recs = cpu_baseline(x, headline, ns)
-                # the records the one-thread CPU leg just produced against the HIP path on the same samples
+                # the records the one-thread CPU leg just produced against the HIP path on the same samples ...
                 out["parity_in_run"] = parity_in_run(x, headline, ns, device, fmt, want=cpu_recs)
+                if headline in PARITY_FULL and args.parity != "prefix" and ns < n:
+                    # ... and the WHOLE capture: the oracle as one segment on every host thread, outside the timed region
+                    out["parity_in_run"] = dict(parity_in_run(x, headline, n, device, fmt), cpu_leg_prefix=out["parity_in_run"])
         del x
         torch.cuda.empty_cache()
         if world == 1 and args.workload is None and not args.no_others:
             others = {}
             k = max(3, min(args.steps, 10))
             for name in ("cfg2", "cfg4", "zigbee1"):
-                r, _ = run_workload(name, int(WORKLOADS[name][3]), k, 1, device, 0, 1,
-                                    parity_samples=0 if args.no_cpu else int(CPU_SAMPLES[name]) // 4)
+                nn = int(WORKLOADS[name][3])
+                r, _ = run_workload(name, nn, k, 1, device, 0, 1,
+                                    parity_samples=0 if args.no_cpu else (nn if (name in PARITY_FULL and args.parity != "prefix")
+                                                                          else int(CPU_SAMPLES[name]) // 4))
                 others[name] = {f: r[f] for f in r if f in ("workload", "value", "unit", "ms_per_step", "steps", "kernel",
                                                   "kernel_ms", "frac", "achieved_GBps", "packets_per_gpu",
                                                   "decoded_crc_ok_per_gpu", "min_expected_crc_ok_per_gpu", "parity_in_run")}

@@ -48,7 +48,8 @@ def test_headline_is_the_wideband_metric():
     assert rf["fp32_frac"] == rf["fp32"]["frac"]                          # flat copy for the driver's parser
     # parity in the same run: the records of the CPU leg's samples against the HIP path's, set equality
     pr = d["parity_in_run"]
-    assert pr["equal"] is True and pr["workload"] == "cfg3" and pr["samples"] == 4000000 and pr["records"] > 100
+    assert pr["equal"] is True and pr["workload"] == "cfg3" and pr["samples"] == 40000000 and pr["whole_capture"] is True
+    assert pr["records"] > 1000 and pr["cpu_leg_prefix"]["equal"] is True and pr["cpu_leg_prefix"]["samples"] == 4000000
     assert rf["traffic"] is None                                           # the PMC figure is for the full-size workload
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and d["value"] > 20 * cb["value"]
@@ -65,7 +66,12 @@ def test_default_run_carries_every_workload():
         assert w["kernel"] == kern and w["value"] > 0 and w["kernel_ms"] > 0 and 0 < w["frac"] < 1
         assert w["decoded_crc_ok_per_gpu"] >= w["min_expected_crc_ok_per_gpu"] > 0
         assert w["parity_in_run"]["equal"] is True and w["parity_in_run"]["records"] > 100
-    assert d["parity_in_run"]["equal"] is True and d["parity_in_run"]["samples"] == 40 * (1 << 21)
+    # the WHOLE 8e8-sample capture against the oracle (one segment, every host thread), and the timed CPU leg's prefix
+    pr = d["parity_in_run"]
+    assert pr["equal"] is True and pr["samples"] == 800000000 and pr["whole_capture"] is True and pr["records"] == d["config"]["packets_per_gpu"]
+    assert pr["cpu_leg_prefix"]["equal"] is True and pr["cpu_leg_prefix"]["samples"] == 40 * (1 << 21)
+    assert ow["cfg2"]["parity_in_run"]["samples"] == 1000000000 and ow["cfg4"]["parity_in_run"]["samples"] == 320000000
+    assert ow["cfg2"]["parity_in_run"]["records"] == ow["cfg2"]["packets_per_gpu"]
     assert ow["cfg5"]["segments_per_gpu"] == 48 + 20 and ow["cfg5"]["decoded_crc_ok"] >= ow["cfg5"]["min_expected_crc_ok"] > 0
     assert ow["cfg5"]["segments_per_submission"] == {"btle": 48, "zigbee": 20}
 

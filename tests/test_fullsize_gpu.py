@@ -1,7 +1,9 @@
-"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot run
-8 GB in seconds): encode -> channel -> decode round trips, no invented packets, ordering,
-idempotence.  Workloads are built like bench.py's: a seeded noise-free tile of real traffic
-repeated on the device plus independent AWGN per sample."""
+"""Parity at BASELINE.json's full sizes: (1) through size-independent properties -- encode -> channel -> decode round
+trips, no invented packets, ordering, idempotence -- and (2), round 4, against the ORACLE ITSELF on the whole capture:
+with every host thread inside the channelizer and one per bin the oracle decodes the 8e8-sample wideband capture as ONE
+segment in seconds, the 1e9-sample single channel in its scalar loop in ~20 s, so the full-size records are compared
+record for record, byte for byte.  Workloads are built like bench.py's: a seeded noise-free tile of real traffic repeated
+on the device plus independent AWGN per sample."""
 import numpy as np
 import pytest
 
@@ -147,3 +149,72 @@ def test_cfg5_concurrent_wideband_scans_equal_separate_runs():
     assert len(both_b) > 5000 and len(both_z) > 1000
     assert int(both_b["crc_ok"].sum()) >= 0.99 * len(both_b)
     torch.cuda.synchronize()
+
+
+def _same_records(got, want):
+    assert len(got) == len(want)
+
+    def canon(r):
+        return r[np.lexsort((r["len"], r["sample_index"], r["channel"]))]
+    a, b = canon(got), canon(want)
+    for f in ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags", "aux"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(a["bytes"], b["bytes"])
+
+
+def test_cfg3_full_size_records_equal_the_oracle(oracle):
+    """BASELINE.json configs[2] at its full size, 8e8 samples of the 80 Msps band: every record the HIP path decodes --
+    all fields, all bytes -- equals what the CPU oracle decodes from the same 6.4 GB as ONE segment (what the reference's
+    consumer keeps: snout/core/message.py:226)."""
+    from snout_amd.rx import SnoutRx
+    tile, truth = synth.wideband_capture(0, 40 * (1 << 16), seed=3, sigma=0.0)
+    reps = int(8e8) // tile.size + 1
+    x = _tiled(tile, reps, seed=11)[:2 * int(8e8)]
+    with SnoutRx(proto=0, n_channels=40) as rx:
+        got = rx.process(x)
+    host = x.cpu().numpy()
+    del x
+    oracle.set_threads(oracle.hw_threads())
+    try:
+        want = oracle.wideband_segment(host, proto=0)
+    finally:
+        oracle.set_threads(1)
+    assert len(want) > 60000 and int(want["crc_ok"].sum()) >= 0.9 * (int(8e8) // tile.size) * len(truth)
+    _same_records(got, want)
+
+
+def test_cfg2_full_size_records_equal_the_oracle(oracle):
+    """BASELINE.json configs[1] at its full size, 1e9 single-channel samples, record for record against the oracle's one
+    sequential search over the same 8 GB (search_unique_bits resumes behind every examined packet -- there is
+    one such chain over the whole capture, and `btle_resolve` has to reproduce it)."""
+    from snout_amd.rx import SnoutRx
+    tile, truth = synth.btle_capture(1 << 22, channel=37, seed=2, noise=False)
+    n = int(1e9)
+    x = _tiled(tile, n // tile.size + 1, seed=12)[:2 * n]
+    with SnoutRx(proto=0, channel=37) as rx:
+        got = rx.process(x)
+    host = x.cpu().numpy()
+    del x
+    want, _ = oracle.btle_segment(host, channel=37, cap=max(1024, n // 4096))
+    assert len(want) >= (n // tile.size) * len(truth) > 40000
+    _same_records(got, want)
+
+
+def test_cfg4_full_size_records_equal_the_oracle(oracle):
+    """BASELINE.json configs[3] at its full size (3.2e8 samples, all 16 bins busy, slotted traffic): the lanes, the stitching
+    and the sinks of the HIP path against the oracle's on the whole capture, with the lane shape a call of that size gets."""
+    from snout_amd.rx import SnoutRx
+    tile, truth = synth.wideband_capture(1, 16 * (1 << 17), seed=4, sigma=0.0)
+    n = int(3.2e8)
+    x = _tiled(tile, n // tile.size + 1, seed=13)[:2 * n]
+    with SnoutRx(proto=1, n_channels=16) as rx:
+        got = rx.process(x)
+    host = x.cpu().numpy()
+    del x
+    oracle.set_threads(oracle.hw_threads())
+    try:
+        want = oracle.wideband_segment(host, proto=1)
+    finally:
+        oracle.set_threads(1)
+    assert len(want) > 10000
+    _same_records(got, want)
