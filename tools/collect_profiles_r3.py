@@ -1,6 +1,6 @@
 """Everything under profiles/r3_* from the rocprofv3 outputs of tools/refresh_profiles_r3.sh
 (gpurun_out/r3prof/*): kernel stats of every workload, HBM traffic of the dominant kernels
-(r2_traffic.json, read by bench.py), SQ counters of the channelizer."""
+(r3_traffic.json, read by bench.py), SQ counters of the channelizer."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
