@@ -92,7 +92,11 @@ typedef struct snout_rx_cfg {
     uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 512;
                                  multiples of 64, warm-up < core; the timing loop needs >= 256.
                                  BOTH 0: chosen per call by its size (snout_zigbee_lane_shape): core 4096
-                                 from 2^29 channel samples (channels x samples) per call, else 2048      */
+                                 from 2^29 channel samples (channels x samples x segments of a batch) per
+                                 call, else 2048.  The decoded frame set is a function of the shape (DESIGN.md
+                                 section 6-3): a capture fed in one call, in segments, or in batches of other
+                                 sizes can decode differently by a fraction of a percent of its frames unless
+                                 zb_core / zb_warmup are set explicitly                                  */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
     uint32_t flags;           /* SNOUT_CFG_* bits                                                */
@@ -245,7 +249,7 @@ int  snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap);
 /* Channel plans (a10). */
 double   snout_zigbee_center_hz(uint32_t channel);   /* 1e6*(2400+5*(ch-10)), top_block.py:56,94-96 */
 /* The 802.15.4 lane shape a handle with cfg.zb_core = cfg.zb_warmup = 0 uses for a call of `channel_samples`
- * (channels x channel samples of one segment of the call): the clock recovery (clock_recovery_mm_ff, top_block.py:69) runs in lanes of
+ * (channels x channel samples per segment x segments of the submission): the clock recovery (clock_recovery_mm_ff, top_block.py:69) runs in lanes of
  * `core` samples that start `warmup` samples early; long calls get the longer shape.  Results are a function of the
  * shape, so a checker has to run the same one. */
 void     snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup);

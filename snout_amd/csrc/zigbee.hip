@@ -1292,7 +1292,10 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
     if (auto_shape) {
         // cfg.zb_core = cfg.zb_warmup = 0: by the size of the call (snout_zigbee_lane_shape; oracle_py.zb_auto_shape mirrors it)
         uint32_t c_ = 0, w_ = 0;
-        snout_zigbee_lane_shape(n * (uint64_t)seg_slots, &c_, &w_);     // per segment: a batch decodes exactly what its segments decode one by one
+        // by everything the submission carries (channels x samples x segments of a batch): the long shape needs that many lanes
+        // to fill the GPU, and it is the more faithful one (half the seams).  A batch whose total crosses the threshold
+        // therefore decodes with another shape than its segments would one by one; cfg.zb_core pins it.
+        snout_zigbee_lane_shape(n * (uint64_t)seg_slots * segs, &c_, &w_);
         set_shape(c_, w_);
     }
     lanes_per_slot = cdiv(n, core);
