@@ -656,6 +656,9 @@ def main():
     assert torch.cuda.current_device() == local_rank            # LOCAL_RANK -> device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the record exchange is a few MB per step: a few RCCL channels carry it, and every channel is a workgroup that
+        # needs a CU beside the channelizer's persistent grid (which leaves reserved_cus free for them)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:

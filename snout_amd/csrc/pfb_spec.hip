@@ -175,7 +175,11 @@ void pfb_spec(const PfbMfArgs A)
     __shared__ float2 cfirst[BT ? kFftWaves : 1][2][BT ? M * 4 : 1];    // [wave][block parity][channel][phase]: y of the block's first four times
     __shared__ float2 clast[BT ? kFftWaves : 1][BT ? M * 4 : 1];        // ... of its last four
     // 802.15.4: fast_atan2f table, IIR weights, y of each block's last output time, each wave's d values (for the S_j sums)
-    __shared__ float atan_s[ZB ? 257 : 1];
+#ifndef SNOUT_ATAN_PAIR
+#define SNOUT_ATAN_PAIR 0
+#endif
+    __shared__ float atan_s[(ZB && !SNOUT_ATAN_PAIR) ? 257 : 1];
+    __shared__ float2 atan_p[(ZB && SNOUT_ATAN_PAIR) ? 256 : 1];
     __shared__ double wts_s[ZB ? 64 : 1];
     __shared__ float2 ylast[ZB ? kFftWaves : 1][ZB ? M : 1];
     __shared__ float dls[ZB ? kFftWaves : 1][ZB ? M * 65 : 1];
@@ -199,7 +203,8 @@ void pfb_spec(const PfbMfArgs A)
 
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     if constexpr (ZB) {
-        for (int i = t; i < 257; i += 64 * W) atan_s[i] = A.zb.atan_tab[i];
+        if (SNOUT_ATAN_PAIR) { for (int i = t; i < 256; i += 64 * W) atan_p[i] = make_float2(A.zb.atan_tab[i], A.zb.atan_tab[i + 1]); }
+        else { for (int i = t; i < 257; i += 64 * W) atan_s[i] = A.zb.atan_tab[i]; }
         if (t < 64) wts_s[t] = A.zb.iir_w[t];
     }
 #ifdef SNOUT_MF_STAMPS
@@ -352,10 +357,18 @@ void pfb_spec(const PfbMfArgs A)
                         // one tile ago) go to LDS behind this tile's FIR: a load has one tile time + the FIR to arrive
                         if (!DMA && i2 + 2 < NTL) fetch(pre[hb], t_lo + (uint32_t)i2 + 2u);
                         SP_STAMP(0);
+#ifndef SNOUT_SP_STAGGER
+#define SNOUT_SP_STAGGER 0
+#endif
+                        // Stagger (A/B switch): the upper half of the FIR waves stages the next tile BEFORE its FIR, so that the
+                        // barrier does not release ten waves into the same burst of window reads and the two halves' LDS reads /
+                        // FMAs / LDS writes interleave (stage() only reads this tile's input buffer and writes the next one's).
+                        const bool stage_first = SNOUT_SP_STAGGER != 0 && w >= kFirWaves / 2;
+                        if (stage_first && !DMA && i2 + 1 < NTL) stage(pre[hb ^ 1], hb ^ 1);
                         if (hb == 0) fir_tile(std::integral_constant<int, 0>{});
                         else         fir_tile(std::integral_constant<int, 1>{});
                         SP_STAMP(1);
-                        if (!DMA && i2 + 1 < NTL) stage(pre[hb ^ 1], hb ^ 1);
+                        if (!stage_first && !DMA && i2 + 1 < NTL) stage(pre[hb ^ 1], hb ^ 1);
                         SP_STAMP(4);
                     }
                     if constexpr (DMA && SNOUT_SP_DMA == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -606,7 +619,11 @@ void pfb_spec(const PfbMfArgs A)
                             float2 p;
                             p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.x), __float_as_int(y[k].re), 0x138, 0xF, 0xF, false));
                             p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.y), __float_as_int(y[k].im), 0x138, 0xF, 0xF, false));
+#if SNOUT_ATAN_PAIR
+                            float v = zb_discriminate_with(make_float2(y[k].re, y[k].im), p, AtanPairs{atan_p});
+#else
                             float v = zb_discriminate(make_float2(y[k].re, y[k].im), p, atan_s);
+#endif
                             if (mloc >= left) v = 0.0f;
                             if (emit) A.zb.d[(uint64_t)seg * A.segs.d_seg + (uint64_t)k * A.zb.d_stride + mg] = v;
                             dl[k * 65 + l] = v;

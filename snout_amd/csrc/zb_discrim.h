@@ -5,9 +5,22 @@
 
 namespace snout {
 
+// The 257-entry atan table as the kernels hold it in LDS: plain (two 4-byte reads per value: tab[k], tab[k + 1]) or as 256
+// pairs (tab[k], tab[k + 1]) read with ONE 8-byte read -- half the LDS instructions and half the bank-conflict cycles of the
+// lane-random index (SNOUT_ATAN_PAIR in pfb_spec.hip).
+struct AtanPlain {
+    const float* t;
+    __device__ __forceinline__ void get(int k, float& t0, float& t1) const { t0 = t[k]; t1 = t[k + 1]; }
+};
+struct AtanPairs {
+    const float2* p;
+    __device__ __forceinline__ void get(int k, float& t0, float& t1) const { const float2 v = p[k]; t0 = v.x; t1 = v.y; }
+};
+
 // a4: d[t] = fast_atan2f(Im(x[t] conj x[t-1]), Re(...)),  x[-1] = 0.  GNU Radio's table-driven
 // fast_atan2f (257-entry atan table, linear interpolation, octant fix-up).
-__device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* __restrict__ tab)
+template <class Tab>
+__device__ __forceinline__ float fast_atan2f_with(float y, float x, const Tab tab)
 {
     // Straight-line form of the oracle's branches (same operations on the taken path, selected).
     const float ya = fabsf(y), xa = fabsf(x);
@@ -17,8 +30,9 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
     // the oracle's "& 0xff" is the identity here: z is a minimum over a maximum, in [0, 1] or NaN, so a is in
     // [0, 255] or NaN and v_cvt_i32_f32 gives 0..255 (NaN -> 0)
     const int k = (int)a;
-    const float t0 = tab[k];
-    const float interp = t0 + (tab[k + 1] - t0) * (a - (float)k);
+    float t0, t1;
+    tab.get(k, t0, t1);
+    const float interp = t0 + (t1 - t0) * (a - (float)k);
     const float base = z < 0.003921569f ? z : interp;
     const float PI = 3.14159265358979323846f, H = 1.57079632679489661923f;
     const bool xp = x >= 0.0f, yp = y >= 0.0f;
@@ -39,13 +53,23 @@ __device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* 
 
 // d = fast_atan2f(Im(a conj p), Re(a conj p)) with the products rounded first (contraction is off);
 // a non-finite result is defined as 0 (as the oracle).
-__device__ __forceinline__ float zb_discriminate(float2 a, float2 p, const float* __restrict__ tab)
+template <class Tab>
+__device__ __forceinline__ float zb_discriminate_with(float2 a, float2 p, const Tab tab)
 {
     const float re = a.x * p.x + a.y * p.y;
     const float im = a.y * p.x - a.x * p.y;
-    float v = fast_atan2f_tab(im, re, tab);
+    float v = fast_atan2f_with(im, re, tab);
     if (!(fabsf(v) <= 4.0f)) v = 0.0f;
     return v;
+}
+
+__device__ __forceinline__ float fast_atan2f_tab(float y, float x, const float* __restrict__ tab)
+{
+    return fast_atan2f_with(y, x, AtanPlain{tab});
+}
+__device__ __forceinline__ float zb_discriminate(float2 a, float2 p, const float* __restrict__ tab)
+{
+    return zb_discriminate_with(a, p, AtanPlain{tab});
 }
 
 }  // namespace snout

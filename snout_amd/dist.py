@@ -223,6 +223,7 @@ class AsyncRecordGather:
         self.fake = int(fake_world) if (fake_world and fake_world > 1 and self.world == 1) else 0
         self.blocks = self.fake or self.world       # record blocks rank 0 holds after an exchange
         self.cap = int(cap)             # capacity new exchanges are sized for (0: agreed at the first launch)
+        self.expect = None              # record counts of the last finished exchange: what the next download is sized for
         self.pool = []                  # finished slots, oldest first: reused once another has finished (views stay valid until then)
         self.cur = None                 # the open exchange (appends go here)
         self.closed = []                # complete, not yet launched
@@ -411,7 +412,12 @@ class AsyncRecordGather:
                         C.c_void_p(slot["recv"].data_ptr()), W, B, cap, C.c_void_p(heads.data_ptr()), 4, int(self.dedup_tol),
                         C.c_void_p(slot["out"].data_ptr()), C.c_void_p(slot["n_keep"].data_ptr()),
                         C.c_void_p(slot["work"].data_ptr()), slot["work"].numel(), C.c_void_p(self.stream.cuda_stream)))
-                    slot["host"][:B * cap * W].copy_(slot["out"], non_blocking=True)
+                    # the download is sized by what the exchange before delivered (+ 2 % + 256 records): the count of THIS one is
+                    # known on the device only, and every byte of a blit download is CU time taken from the receive path.
+                    # finish() fetches the rest in the rare case that more arrived.
+                    rows = B * cap if self.expect is None else min(B * cap, int(self.expect * 1.02) + 256)
+                    slot["rows_down"] = rows
+                    slot["host"][:rows * W].copy_(slot["out"][:rows * W], non_blocking=True)
                     slot["n_host"].copy_(slot["n_keep"], non_blocking=True)
                 elif self.dedup_tol is not None:
                     rows = slot["recv"].view(B * cap, W).view(torch.int64)
@@ -419,7 +425,12 @@ class AsyncRecordGather:
                     slot["host"].copy_(out.view(torch.uint8).reshape(-1), non_blocking=True)
                     slot["n_host"].copy_(n_keep, non_blocking=True)
                 else:
-                    slot["host"].copy_(slot["recv"], non_blocking=True)
+                    per = cap if self.expect is None else min(cap, int(self.expect * 1.02) + 256)       # rows per rank block
+                    slot["rows_down"] = per
+                    if per == cap:
+                        slot["host"].copy_(slot["recv"], non_blocking=True)
+                    else:               # one strided copy: the first `per` rows of every block
+                        slot["host"].view(B, cap * W)[:, :per * W].copy_(slot["recv"].view(B, cap * W)[:, :per * W], non_blocking=True)
             if self.on_gpu:
                 slot["ev"].record(self.stream)
         self.inflight.append(slot)
@@ -484,12 +495,21 @@ class AsyncRecordGather:
             return None
         if self.dedup_tol is not None:
             n = int(slot["n_host"].item())
+            down = slot.get("rows_down")
+            if down is not None and n > down:           # more than the download was sized for: fetch the rest now
+                slot["host"][down * W:n * W].copy_(slot["out"][down * W:n * W])
+            self.expect = n
             out = slot["host"].numpy()[:n * W].view(self.dtype)
             if rest is not None:        # rare: merge the remainder with the host rule
                 out = dedup_records(np.concatenate([out, rest]), tol=int(self.dedup_tol))
             return [out] if views else out.copy()     # a view is valid until the next finish()
-        host = slot["host"].numpy().reshape(B, cap * W)
         allc = [int(c) for c in h2[:, 0]]
+        down = slot.get("rows_down")
+        most = min(max(allc), cap)
+        if down is not None and most > down:            # more than the download was sized for: fetch the rest now
+            slot["host"].view(B, cap * W)[:, down * W:most * W].copy_(slot["recv"].view(B, cap * W)[:, down * W:most * W])
+        self.expect = most
+        host = slot["host"].numpy().reshape(B, cap * W)
         parts = [host[r, :min(allc[r], cap) * W].view(self.dtype) for r in range(B)]
         if rest is not None:
             parts.append(rest)

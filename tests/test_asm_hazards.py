@@ -33,6 +33,10 @@ _Zk:
     for bad in (early_read, early_write, partial):
         problems, _ = chk.check(bad)
         assert len(problems) == 1
+    # LDS writes count in lgkmcnt as well: behind read, write, lgkmcnt(1) the read is back
+    wr = ok.replace("v_add_f32_e32 v9, v8, v7\n\ts_waitcnt lgkmcnt(1)\n\tv_add_f32_e32 v9, v2, v3",
+                    "ds_write_b64 v1, v[20:21]\n\ts_waitcnt lgkmcnt(1)\n\tv_add_f32_e32 v9, v2, v5")
+    assert wr != ok and chk.check(wr)[0] == []
     # a scalar load in flight shares the counter and returns out of order: only lgkmcnt(0) counts then
     smem = ok.replace("ds_read_b64 v[4:5], v1 offset:16", "ds_read_b64 v[4:5], v1 offset:16\n\ts_load_dwordx2 s[0:1], s[4:5], 0x0")
     assert len(chk.check(smem)[0]) == 1

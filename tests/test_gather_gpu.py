@@ -104,3 +104,32 @@ def test_exchange_object_on_the_gpu(tol, fake):
         order = np.lexsort((first["sample_index"], first["channel"], first["proto"]))
         assert np.array_equal(order, np.arange(len(first)))
         assert first.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("tol", [None, 0])
+def test_downloads_sized_by_the_exchange_before_still_deliver_everything(tol):
+    """Rank 0 downloads what the exchange before delivered (+ 2 %): when an exchange brings more, finish() fetches the
+    rest -- nothing is ever cut off."""
+    import torch
+    rng = np.random.default_rng(4)
+    dt, blocks, _ = _blocks(rng, 160, 0, 1, 3000, [3000])
+    recs = sdist.widen_records(blocks[0])
+    recs["sample_index"] = np.arange(len(recs), dtype=np.uint64) * 7           # all distinct: nothing de-duplicates away
+    recs["channel"] = 3
+    recs["proto"] = 1                                                            # one sort key order = the order appended
+    g = sdist.AsyncRecordGather(torch.device("cuda", 0), width=160, dedup_tol=tol, cap=3200, fake_world=2)
+    sizes = [100, 100, 2900, 2900, 40, 3000, 0, 1500]
+    outs = []
+    for n in sizes:
+        if len(g.inflight) == 2:
+            outs.append(g.finish())
+        g.begin()
+        g.append(recs[:n])
+        g.launch()
+    while g.inflight:
+        outs.append(g.finish())
+    assert [len(o) for o in outs] == [2 * n for n in sizes]
+    for n, o in zip(sizes, outs):
+        o = sdist.widen_records(o)
+        first = o[o["sample_index"] < (1 << 40)]
+        assert first.tobytes() == recs[:n].tobytes()

@@ -34,7 +34,7 @@ def split_ops(rest: str):
 
 def check(text: str):
     problems, kernel = [], None
-    pending = []            # [(set of registers, line number)] in issue order (LDS reads only)
+    pending = []            # [(registers an LDS read will fill, line number)] of every outstanding LDS operation, in issue order
     smem = 0
     n_reads = 0
     for ln, line in enumerate(text.splitlines(), 1):
@@ -81,6 +81,8 @@ def check(text: str):
         if is_lds_read and ops:
             pending.append((regs(ops[0]), ln))
             n_reads += 1
+        elif op.startswith("ds_"):
+            pending.append((set(), ln))         # LDS writes / atomics count in lgkmcnt too (in order with the reads)
     return problems, n_reads
 
 
