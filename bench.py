@@ -274,7 +274,8 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
     on_dev = gather is not None and gather.on_gpu
     rcus = reserved_cus(world, gather.fake if gather is not None else 0) if n_ch > 1 else 0
     rx = SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt, records_on_device=on_dev,
-                 reserved_cus=rcus)
+                 reserved_cus=rcus, zb_core=int(os.environ.get("SNOUT_BENCH_ZB_CORE", "0")),
+                 zb_warmup=int(os.environ.get("SNOUT_BENCH_ZB_WARMUP", "0")))        # dev aid: 802.15.4 lane shape (0 = the default rule)
 
     gathered = [0, 0]                   # exchanges finished on rank 0, records in the last one
 

@@ -277,8 +277,12 @@ static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_
     float mu = 0.5f, omega = 2.0f, last = 0.0f;
     float win[8], ring[16];
     uint64_t ii = s0, z_next = s0, chips = 0;
+    {   /* ANALYSIS SWITCH (tools/lane_residual_r4.py only): start the lane's loop this many quarter samples later */
+        const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_PHASE0") : NULL;
+        if (e) { const int q = atoi(e); ii += (uint64_t)(q / 4); mu = 0.5f + 0.25f * (float)(q % 4); if (mu >= 1.0f) { mu -= 1.0f; ii++; } }
+    }
     while (ii < core_end && ii + 8 <= n) {
-        while (z_next < ii + 8) {
+        while (z_next < ii + 8 && z_next < n) {
             const float x = d[z_next];
             lp = alpha * (double)x + one_minus * lp;
             const float z = x - (float)lp;

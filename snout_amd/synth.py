@@ -270,14 +270,16 @@ def zigbee_capture(n_samples: int, channel: int = 11, seed: int = 4, mean_gap: f
                    sigma: float = 0.05, cfo_max_hz: float = 50e3, fs: float = 4e6,
                    amplitude: float = 1.0, n_packets: Optional[int] = None, min_len: int = 5,
                    max_len: int = 127, noise: bool = True, tail_guard: int = 4096,
-                   slot_phase: Optional[int] = None) -> Tuple[np.ndarray, List[TruthPacket]]:
+                   slot_phase: Optional[int] = None, slot_jitter: int = 0) -> Tuple[np.ndarray, List[TruthPacket]]:
     """Single 802.15.4 channel at 4 Msps (2 samples/chip): AWGN + frames with valid FCS separated
     by exponential gaps (SURVEY §8d cfg #4, per channel).
 
     ``slot_phase`` (0 or 1): slotted traffic as in a TSCH schedule -- time is cut into timeslots of
     ZB_SLOT samples, this channel transmits only in the slots of its phase (even / odd), one frame
-    per used slot, starting at the slot boundary + 64 samples; slots are used with the probability
-    that keeps the mean frame rate of the unslotted model."""
+    per used slot, starting at the slot boundary + 64 samples (+ a random 0 .. ``slot_jitter`` - 1 samples: without it every
+    transmitter of a slotted capture shares ONE chip clock phase, which no set of real radios does -- a receiver's
+    timing loop then stays locked from one frame, even a neighbour's leakage, to the next); slots are used with the
+    probability that keeps the mean frame rate of the unslotted model."""
     rng = np.random.default_rng(seed)
     x = np.zeros(n_samples, dtype=np.complex64)
     truth: List[TruthPacket] = []
@@ -292,6 +294,8 @@ def zigbee_capture(n_samples: int, channel: int = 11, seed: int = 4, mean_gap: f
                 break
             if rng.random() >= p_use:
                 continue
+            if slot_jitter:
+                start += int(rng.integers(0, slot_jitter))
             ln = int(rng.integers(min_len, max_len + 1))
             psdu = zb_frame(bytes(rng.integers(0, 256, ln - 2, dtype=np.uint8)))
             wave = oqpsk_modulate(psdu)
@@ -355,7 +359,7 @@ def zigbee_bin_channel(b: int) -> int:
 
 def wideband_capture(proto: int, n_samples: int, seed: int = 3, bins: Optional[Sequence[int]] = None,
                      mean_gap: float = 20000.0, sigma: float = 0.05, cfo_max_hz: float = 50e3,
-                     max_len: int = 127, slotted: Optional[bool] = None) -> Tuple[np.ndarray, List[TruthPacket]]:
+                     max_len: int = 127, slotted: Optional[bool] = None, slot_jitter: int = 0) -> Tuple[np.ndarray, List[TruthPacket]]:
     """Wideband synthetic capture (SURVEY §8d cfg #3 / #4): every listed channelizer bin carries an
     independent narrowband 4 Msps traffic stream, upsampled by M/2... i.e. to fs = M * 2 MHz, shifted
     to its bin centre (bin b -> b fs / M, wrapping) and summed; AWGN added at the wideband rate.
@@ -381,7 +385,7 @@ def wideband_capture(proto: int, n_samples: int, seed: int = 3, bins: Optional[S
             use_slots = (len(bins) > 8) if slotted is None else slotted
             nb, tr = zigbee_capture(n_ch, channel=ch, seed=seed * 1000 + b, mean_gap=mean_gap,
                                     noise=False, cfo_max_hz=cfo_max_hz, max_len=max_len,
-                                    slot_phase=(b & 1) if use_slots else None)
+                                    slot_phase=(b & 1) if use_slots else None, slot_jitter=slot_jitter)
         wb = _upsample_to_wideband(nb, up)
         rot = np.exp(2j * np.pi * ((b * t) % M) / M).astype(np.complex64)
         x[:wb.size] += wb * rot
