@@ -277,6 +277,8 @@ static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_
     float mu = 0.5f, omega = 2.0f, last = 0.0f;
     float win[8], ring[16];
     uint64_t ii = s0, z_next = s0, chips = 0;
+    float warm_gain = 1.0f;
+    { const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_WARMGAIN") : NULL; if (e) warm_gain = (float)atof(e); }
     {   /* ANALYSIS SWITCH (tools/lane_residual_r4.py only): start the lane's loop this many quarter samples later */
         const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_PHASE0") : NULL;
         if (e) { const int q = atoi(e); ii += (uint64_t)(q / 4); mu = 0.5f + 0.25f * (float)(q % 4); if (mu >= 1.0f) { mu -= 1.0f; ii++; } }
@@ -306,7 +308,7 @@ static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_
             const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
             omega = omega_mid + c;
         }
-        mu = mu + omega + gain_mu * mm;
+        mu = mu + omega + (ii < core_start ? gain_mu * warm_gain : gain_mu) * mm;
         const float fl = floorf(mu);
         ii += fl >= 1.0f ? (uint64_t)(int)fl : 1u;     /* 1..3 for finite input */
         mu = mu - fl;
