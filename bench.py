@@ -247,11 +247,13 @@ def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=No
 
 
 def reserved_cus(world: int, fake: int) -> int:
-    """Compute units the channelizer's persistent grid leaves free when a record gather runs beside it (N > 1, or the
-    fake-world rehearsal): the RCCL kernels, the de-duplication and the record download then do not wait for a channelizer
-    launch to end.  8 = one per XCD; SNOUT_BENCH_RESERVED_CUS overrides."""
+    """Compute units the channelizer's persistent grid leaves free (cfg.reserved_cus).  Built for the record gather of
+    N > 1 -- so that the RCCL kernels, the de-duplication and the record download would not wait for a channelizer
+    launch to end -- and measured in the 8-rank rehearsal (profiles/r4_fake_world.txt): it costs what it reserves (8 CUs:
+    + 1-2.6 % on the headline step) and buys nothing, because the runtime's copy kernels spread over whatever is free between
+    two launches either way.  Default 0 at every N; SNOUT_BENCH_RESERVED_CUS sets it."""
     e = os.environ.get("SNOUT_BENCH_RESERVED_CUS")
-    return int(e) if e is not None else (8 if (world > 1 or fake > 1) else 0)
+    return int(e) if e is not None else 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -416,7 +418,7 @@ def read_peak(x, device):
 def traffic_from_profiles(workload: str, kernel: str, n: int):
     """PMC-derived HBM bytes per launch of the same kernel / workload, from the committed profile
     pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected); None when there is none."""
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

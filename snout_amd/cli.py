@@ -139,7 +139,7 @@ def _scan_options(f):
                      help="wideband: cut the capture into overlapping segments, one GPU per rank "
                           "(run under torch.distributed.run), records gathered on rank 0"),
         click.option("--segment", type=int, default=1 << 24, help="wideband: input samples per segment"),
-        click.option("--batch", type=click.IntRange(1, 8), default=4,
+        click.option("--batch", type=click.IntRange(1, 64), default=4,
                      help="wideband: segments handed to the GPU as one submission"),
         click.option("-f", "--filename", default=None, help="dump file"),
         click.option("--iq", callback=_iq_path, default=None,
@@ -184,12 +184,18 @@ def zigbee():
 @zigbee.command("scan")
 @_scan_options
 @click.option("--udp", is_flag=True, help="send RFtap datagrams to 127.0.0.1:52002 (scapy-radio)")
+@click.option("--lane-core", type=int, default=0,
+              help="clock-recovery lane length in channel samples (multiple of 64; 0: by the size of the call). The reference's "
+                   "receiver is ONE sequential loop: longer lanes and warm-ups decode closer to it, slower (DESIGN.md 6-3)")
+@click.option("--lane-warmup", type=int, default=0, help="samples a lane's timing loop starts before its core (multiple of 64; 0: 512)")
 def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, batch, filename, iq, fmt, synthetic,
-                seconds, udp):
+                seconds, udp, lane_core, lane_warmup):
     chs = parse_channels(channels, "zigbee")
     packets, timeout = stop_conditions("zigbee", packets, timeout)
-    scan = ZigbeeScan(channels=chs, source=_source("zigbee", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment, batch),
-                      timeout=timeout, packet_threshold=packets, udp=udp)
+    src = _source("zigbee", iq, synthetic, chs, seconds, fmt, wideband, sharded, segment, batch)
+    if lane_core or lane_warmup:
+        src.rx_kw = dict(zb_core=lane_core, zb_warmup=lane_warmup)
+    scan = ZigbeeScan(channels=chs, source=src, timeout=timeout, packet_threshold=packets, udp=udp)
     def show(message):
         from .formats import parse_mhr
         try:

@@ -187,7 +187,7 @@ class WidebandSource(IqSource):
         self.segment = int(segment)
         self.sharded = bool(sharded)
         self.device = device
-        self.batch = max(1, min(8, int(batch)))   # segments per submission (snout_rx_submit_batch_dev)
+        self.batch = max(1, min(64, int(batch)))  # segments per submission (snout_rx_submit_batch_dev)
         self.rank = 0
         self._rec = None
 
@@ -214,7 +214,7 @@ class WidebandSource(IqSource):
         dev = torch.device("cuda", torch.cuda.current_device())
         M = 40 if self.proto == _ffi.PROTO_BTLE else 16
         sc = ShardedScan(self.proto, n_channels=M, seg_len=self.segment, device=self.device,
-                         batch=self.batch, sample_format=self.sample_format)
+                         batch=self.batch, sample_format=self.sample_format, **getattr(self, "rx_kw", {}))
 
         def source(a, b):
             chunk = np.ascontiguousarray(x[a:b])
@@ -400,7 +400,7 @@ class ZigbeeScan:
             return
         if hasattr(self.source, "segments"):         # a live stream: segments as they arrive, timeout by the wall clock
             t_start = time.time()
-            for rec in self.source.segments(_ffi.PROTO_ZIGBEE, channel, self.device):
+            for rec in self.source.segments(_ffi.PROTO_ZIGBEE, channel, self.device, **getattr(self.source, "rx_kw", {})):
                 for p in rec:
                     self._elapsed = time.time() - t_start
                     yield p
@@ -413,7 +413,7 @@ class ZigbeeScan:
         # segments after the first start four DC-filter time constants early and leave what they find
         # there to the segment before (ShardedScan: ZIGBEE_PREROLL_CH, the same rule as the sharded scan)
         for rec in _pipelined_segments(_ffi.PROTO_ZIGBEE, channel, x, getattr(self.source, "sample_format", 0),
-                                       self.device):
+                                       self.device, **getattr(self.source, "rx_kw", {})):      # e.g. the lane shape (cli --lane-core)
             fresh = []
             for p in rec:
                 si = int(p["sample_index"])

@@ -63,7 +63,7 @@ def main(budget_s):
         done[kind] += 1
         if kind in ("btle40", "zigbee16"):
             # batches: equal lengths; up to two batches in flight
-            B = int(rng.integers(2, 9))
+            B = int(rng.integers(2, 9)) if rng.random() < 0.6 else int(rng.integers(9, 65))       # up to 64 segments per submission (round 4)
             n = int(rng.integers(lo * 4, n_tot // 2))
             subs = []
             for _ in range(int(rng.integers(2, 5))):
