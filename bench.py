@@ -447,10 +447,12 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     fake = int(os.environ.get("SNOUT_BENCH_FAKE_WORLD", "0")) if world == 1 else 0
     reserved = reserved_cus(world, fake)
     sb = ShardedScan(0, n_channels=40, seg_len=SEG, device=device.index, handles=int(os.environ.get("SNOUT_CFG5_HB", "1")),
-                     batch=int(os.environ.get("SNOUT_CFG5_BB", "48")), depth=3, records_on_device=on_gpu, reserved_cus=reserved)
+                     batch=int(os.environ.get("SNOUT_CFG5_BB", "48")), depth=3, records_on_device=on_gpu, reserved_cus=reserved,
+                     stream_priority=int(os.environ.get("SNOUT_CFG5_BPRIO", "0")))
     sz = ShardedScan(1, n_channels=16, seg_len=SEG, device=device.index, handles=int(os.environ.get("SNOUT_CFG5_HZ", "1")),
                      batch=int(os.environ.get("SNOUT_CFG5_BZ", "20")), depth=3, records_on_device=on_gpu, reserved_cus=reserved,
-                     zb_core=int(os.environ.get("SNOUT_CFG5_ZB_CORE", "0")), zb_warmup=int(os.environ.get("SNOUT_CFG5_ZB_WARMUP", "0")))
+                     zb_core=int(os.environ.get("SNOUT_CFG5_ZB_CORE", "0")), zb_warmup=int(os.environ.get("SNOUT_CFG5_ZB_WARMUP", "0")),
+                     stream_priority=int(os.environ.get("SNOUT_CFG5_ZPRIO", "-1")))
     # The virtual capture is N x `seconds` long and tile-periodic with a period that divides the
     # segment length, so every segment starts on a tile boundary: the overlap a rank reads behind its
     # segment i shows the same packets as the start of segment i+1 on the next rank (only the noise

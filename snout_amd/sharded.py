@@ -35,7 +35,7 @@ class ShardedScan:
     feed a GPU ``sink``): the handles keep their records in device memory and ``collect`` hands out counts."""
 
     def __init__(self, proto: int, n_channels: int = 1, channel: int = 37, seg_len: int = 1 << 24,
-                 device: int = -1, handles: int = 1, batch: int = 1, depth: int = 2, **rx_kw):
+                 device: int = -1, handles: int = 1, batch: int = 1, depth: int = 2, stream_priority: int = 0, **rx_kw):
         self.proto = proto
         self.n_channels = n_channels
         self.decim = n_channels // 2 if n_channels > 1 else 1
@@ -47,6 +47,7 @@ class ShardedScan:
         pre = 0 if proto == PROTO_BTLE else ZIGBEE_PREROLL_CH * self.decim
         self.preroll = (pre + step - 1) // step * step                # in input samples
         self.batch = max(1, int(batch))
+        self.stream_priority = int(stream_priority)                   # of the handles' streams (-1: high: the scan's small kernels go first)
         self.depth = max(1, min(3, int(depth)))                       # submissions in flight per handle (the library holds 3)
         if self.batch > 1:
             rx_kw = dict(rx_kw, batch_segments=self.batch)
@@ -81,7 +82,7 @@ class ShardedScan:
         import torch
         if self._streams is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-            self._streams = [torch.cuda.Stream(device=dev) for _ in self.rxs]
+            self._streams = [torch.cuda.Stream(device=dev, priority=self.stream_priority) for _ in self.rxs]
             self._jobs = collections.deque()        # submissions not yet submitted
             self._flight = collections.deque()      # submitted, not yet collected
             self._next = self._done = 0             # submissions submitted / collected since the handles were made
