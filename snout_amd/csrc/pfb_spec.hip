@@ -107,6 +107,94 @@ __device__ __forceinline__ void dft5(const cf b[5], cf X[5], const float C1, con
     X[3] = cf{a2.re - s2.im, a2.im + s2.re};
 }
 
+// ---- The same FFT on (re, im) register pairs with the packed f32 instructions (v_pk_add / mul / fma_f32: both halves of a
+// complex value in one issue slot; op_sel swaps the halves and neg_lo / neg_hi negate one of them, so +-j rotations and
+// subtractions are free).  Every component goes through exactly the operations of cf's functions above, in the same order
+// (a - b = a + (-b), (-x) c = -(x c) and a + b = b + a are exact), so the results are the same bits.  On gfx950 a packed
+// instruction occupies the vector pipe for as long as the two plain ones it replaces (tools/fmabench.hip: v_fma_f32 and
+// v_pk_fma_f32 reach the same flop rate), but a wave issues one instruction every five to six cycles at best, and the FFT
+// waves' 1 000 issue slots per 64-time block become 580.
+#ifndef SNOUT_SP_PACKED
+#define SNOUT_SP_PACKED 1
+#endif
+typedef v2f pc;
+__device__ __forceinline__ uint64_t pk2(float lo, float hi) { return ((uint64_t)__float_as_uint(hi) << 32) | (uint64_t)__float_as_uint(lo); }
+__device__ __forceinline__ pc padd(pc a, pc b) { pc r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pc psub(pc a, pc b) { pc r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a - j b = {a.re + b.im, a.im - b.re};  a + j b = {a.re - b.im, a.im + b.re}
+__device__ __forceinline__ pc padd_mj(pc a, pc b) { pc r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pc padd_pj(pc a, pc b) { pc r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// {a.re + b.lo, a.im - b.hi};  {a.re - b.lo, a.im + b.hi}
+__device__ __forceinline__ pc padd_nh(pc a, pc b) { pc r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ pc padd_nl(pc a, pc b) { pc r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// {a.im - a.re, a.re + a.im}
+__device__ __forceinline__ pc pdiff_sum(pc a) { pc r; asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(r) : "v"(a)); return r; }
+// a * k.lo / a * k.hi (both halves);  k = an SGPR pair
+__device__ __forceinline__ pc pmul_lo(pc a, uint64_t k) { pc r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(k)); return r; }
+__device__ __forceinline__ pc pmul_hi(pc a, uint64_t k) { pc r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "s"(k)); return r; }
+// k.lo * a + c;  k.hi * a + c;  -(k.lo) * a + c
+__device__ __forceinline__ pc pfma_lo(uint64_t k, pc a, pc c) { pc r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "s"(k), "v"(a), "v"(c)); return r; }
+__device__ __forceinline__ pc pfma_hi(uint64_t k, pc a, pc c) { pc r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "s"(k), "v"(a), "v"(c)); return r; }
+__device__ __forceinline__ pc pfma_nlo(uint64_t k, pc a, pc c) { pc r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "s"(k), "v"(a), "v"(c)); return r; }
+// a (c + j d): re = fma(a.re, c, -(a.im d)), im = fma(a.re, d, a.im c);  k = {c, d}
+__device__ __forceinline__ pc pmul_tw(pc a, uint64_t k)
+{
+    pc t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(k));                       // {a.im d, a.im c}
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "s"(k), "v"(t));       // {a.re c - t.lo, a.re d + t.hi}
+    return r;
+}
+__device__ __forceinline__ void dft4(const pc b[4], pc X[4])
+{
+    const pc s0 = padd(b[0], b[2]), s1 = psub(b[0], b[2]);
+    const pc s2 = padd(b[1], b[3]), s3 = psub(b[1], b[3]);
+    X[0] = padd(s0, s2);
+    X[2] = psub(s0, s2);
+    X[1] = padd_mj(s1, s3);
+    X[3] = padd_pj(s1, s3);
+}
+__device__ __forceinline__ void dft8(const pc a[8], pc X[8])
+{
+    const uint64_t cc = pk2(0.70710678118654752440f, 0.70710678118654752440f);
+    const pc e[4] = {a[0], a[2], a[4], a[6]}, o[4] = {a[1], a[3], a[5], a[7]};
+    pc E[4], O[4];
+    dft4(e, E);
+    dft4(o, O);
+    const pc T1 = pmul_lo(padd_mj(O[1], O[1]), cc);          // {(re + im) c, (im - re) c}
+    const pc U3 = pmul_lo(pdiff_sum(O[3]), cc);              // {(im - re) c, (re + im) c}: T[3] = {U3.lo, -U3.hi}
+    X[0] = padd(E[0], O[0]);     X[4] = psub(E[0], O[0]);
+    X[1] = padd(E[1], T1);       X[5] = psub(E[1], T1);
+    X[2] = padd_mj(E[2], O[2]);  X[6] = padd_pj(E[2], O[2]);  // T[2] = -j O[2]
+    X[3] = padd_nh(E[3], U3);    X[7] = padd_nl(E[3], U3);
+}
+// cs = {C1, C2}, ss = {S1, S2}
+__device__ __forceinline__ void dft5(const pc b[5], pc X[5], const uint64_t cs, const uint64_t ss)
+{
+    const pc t1 = padd(b[1], b[4]), t2 = padd(b[2], b[3]), t3 = psub(b[1], b[4]), t4 = psub(b[2], b[3]);
+    X[0] = padd(padd(b[0], t1), t2);
+    const pc a1 = pfma_hi(cs, t2, pfma_lo(cs, t1, b[0]));
+    const pc a2 = pfma_lo(cs, t2, pfma_hi(cs, t1, b[0]));
+    const pc s1 = pfma_hi(ss, t4, pmul_lo(t3, ss));
+    const pc s2 = pfma_nlo(ss, t4, pmul_hi(t3, ss));
+    X[1] = padd_mj(a1, s1);
+    X[4] = padd_pj(a1, s1);
+    X[2] = padd_mj(a2, s2);
+    X[3] = padd_pj(a2, s2);
+}
+__device__ __forceinline__ float re_of(cf a) { return a.re; }
+__device__ __forceinline__ float im_of(cf a) { return a.im; }
+__device__ __forceinline__ float re_of(pc a) { return a.x; }
+__device__ __forceinline__ float im_of(pc a) { return a.y; }
+#if SNOUT_SP_PACKED
+typedef pc cx;
+__device__ __forceinline__ cx mk(float re, float im) { return pc{re, im}; }
+__device__ __forceinline__ cx mul_tw(cx a, float c, float d) { return pmul_tw(a, pk2(c, d)); }
+#else
+typedef cf cx;
+__device__ __forceinline__ cx mk(float re, float im) { return cf{re, im}; }
+__device__ __forceinline__ cx mul_tw(cx a, float c, float d) { return cmul_tw(a, c, d); }
+#endif
+
 // Workgroup barrier that orders LDS traffic only (vector-memory loads and stores stay in flight).
 __device__ __forceinline__ void lds_barrier()
 {
@@ -457,26 +545,26 @@ void pfb_spec(const PfbMfArgs A)
                 const bool need = emit || half == 0;
                 const int par = kblk & 1;
                 // ---- Q1: the row, 8-point DFTs over n1 and the twiddles W_40^{n2 k1}
-                cf Bv[M2][M1];
+                cx Bv[M2][M1];
                 if (need) {
                     const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
-                    cf u[M];
+                    cx u[M];
     #pragma unroll
                     for (int q = 0; q < M / 2; q++) {
                         const float4 v = rowp[q];
-                        u[2 * q] = cf{v.x, v.y};
-                        u[2 * q + 1] = cf{v.z, v.w};
+                        u[2 * q] = mk(v.x, v.y);
+                        u[2 * q + 1] = mk(v.z, v.w);
                     }
     #pragma unroll
                     for (int n2 = 0; n2 < M2; n2++) {
-                        cf a[M1], X[M1];
+                        cx a[M1], X[M1];
     #pragma unroll
                         for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
                         dft8(a, X);
     #pragma unroll
                         for (int k1 = 0; k1 < M1; k1++) {
                             const int jj = (n2 * k1) % M;
-                            Bv[n2][k1] = jj == 0 ? X[k1] : cmul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
+                            Bv[n2][k1] = jj == 0 ? X[k1] : mul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
                         }
                     }
                 }
@@ -485,29 +573,33 @@ void pfb_spec(const PfbMfArgs A)
                 finalize();                       // the block before this one: its successor's first output times are there now
                 uint32_t m_lo = 0, m_hi = 0;
                 auto do_k1 = [&](int k1) {
-                    cf b[M2], Y[M2];
+                    cx b[M2], Y[M2];
     #pragma unroll
                     for (int n2 = 0; n2 < M2; n2++) b[n2] = Bv[n2][k1];
+#if SNOUT_SP_PACKED
+                    dft5(b, Y, pk2(c5_1, c5_2), pk2(s5_1, s5_2));
+#else
                     dft5(b, Y, c5_1, c5_2, s5_1, s5_2);
+#endif
                     if constexpr (BT) {
                         // bit[m] = (I[m] Q[m+4]) > (I[m+4] Q[m]); m + 4 is the next lane of the 16-lane row.  The
                         // factor (-1)^{km} is the same for m and m + 4 and cancels in both products.
     #pragma unroll
                         for (int k2 = 0; k2 < M2; k2++) {
                             const int k = k1 + M1 * k2;
-                            const float qn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].im), 0x101, 0xF, 0xF, true));
-                            const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Y[k2].re), 0x101, 0xF, 0xF, true));
-                            const uint64_t mk = __builtin_amdgcn_ballot_w64((Y[k2].re * qn) > (in * Y[k2].im));
+                            const float qn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(im_of(Y[k2])), 0x101, 0xF, 0xF, true));
+                            const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(re_of(Y[k2])), 0x101, 0xF, 0xF, true));
+                            const uint64_t mk = __builtin_amdgcn_ballot_w64((re_of(Y[k2]) * qn) > (in * im_of(Y[k2])));
                             m_lo = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)mk, k, (int)m_lo);
                             m_hi = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)(mk >> 32), k, (int)m_hi);
                         }
                         const int li = l & 15;
                         if (li == 0) {                                   // first four output times of the block
     #pragma unroll
-                            for (int k2 = 0; k2 < M2; k2++) cfirst[f][par][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
+                            for (int k2 = 0; k2 < M2; k2++) cfirst[f][par][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
                         } else if (li == 15) {                           // last four
     #pragma unroll
-                            for (int k2 = 0; k2 < M2; k2++) clast[f][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(Y[k2].re, Y[k2].im);
+                            for (int k2 = 0; k2 < M2; k2++) clast[f][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
                         }
                     } else {
                         const uint64_t mg = m0b + mloc;
@@ -515,9 +607,9 @@ void pfb_spec(const PfbMfArgs A)
     #pragma unroll
                             for (int k2 = 0; k2 < M2; k2++) {
                                 const int k = k1 + M1 * k2;
-                                cf v = Y[k2];
-                                if ((k & 1) && (mg & 1)) { v.re = -v.re; v.im = -v.im; }
-                                A.y[(uint64_t)k * A.y_stride + mg] = make_float2(v.re, v.im);
+                                float vr = re_of(Y[k2]), vi = im_of(Y[k2]);
+                                if ((k & 1) && (mg & 1)) { vr = -vr; vi = -vi; }
+                                A.y[(uint64_t)k * A.y_stride + mg] = make_float2(vr, vi);
                             }
                         }
                     }
@@ -559,48 +651,48 @@ void pfb_spec(const PfbMfArgs A)
                 const bool emit = tile >= t_begin;                   // the tile before the range only supplies y[m0 - 1]
                 const uint64_t mg = m0b + mloc;
                 // ---- Q1: the row and the FFT; y_k[m] = (-1)^{km} X[k]
-                cf y[M];
+                cx y[M];
                 {
                     const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * part + l) * ROW]);
-                    cf u[M];
+                    cx u[M];
 #pragma unroll
                     for (int q = 0; q < M / 2; q++) {
                         const float4 v = rowp[q];
-                        u[2 * q] = cf{v.x, v.y};
-                        u[2 * q + 1] = cf{v.z, v.w};
+                        u[2 * q] = mk(v.x, v.y);
+                        u[2 * q + 1] = mk(v.z, v.w);
                     }
-                    cf Bv[M2][M1];
+                    cx Bv[M2][M1];
 #pragma unroll
                     for (int n2 = 0; n2 < M2; n2++) {
-                        cf a[M1], X[M1];
+                        cx a[M1], X[M1];
 #pragma unroll
                         for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
                         dft4(a, X);
 #pragma unroll
                         for (int k1 = 0; k1 < M1; k1++) {
                             const int jj = (n2 * k1) % M;
-                            Bv[n2][k1] = jj == 0 ? X[k1] : cmul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
+                            Bv[n2][k1] = jj == 0 ? X[k1] : mul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
                         }
                     }
 #pragma unroll
                     for (int k1 = 0; k1 < M1; k1++) {
-                        cf b[M2], Y[M2];
+                        cx b[M2], Y[M2];
 #pragma unroll
                         for (int n2 = 0; n2 < M2; n2++) b[n2] = Bv[n2][k1];
                         dft4(b, Y);
 #pragma unroll
                         for (int k2 = 0; k2 < M2; k2++) {
                             const int k = k1 + M1 * k2;
-                            cf v = Y[k2];
-                            if ((k & 1) && (mg & 1)) { v.re = -v.re; v.im = -v.im; }
-                            y[k] = v;
+                            float vr = re_of(Y[k2]), vi = im_of(Y[k2]);
+                            if ((k & 1) && (mg & 1)) { vr = -vr; vi = -vi; }
+                            y[k] = mk(vr, vi);
                         }
                     }
                 }
                 if constexpr (ZB) {
                     if (l == 63) {
 #pragma unroll
-                        for (int k = 0; k < M; k++) ylast[f][k] = make_float2(y[k].re, y[k].im);
+                        for (int k = 0; k < M; k++) ylast[f][k] = make_float2(re_of(y[k]), im_of(y[k]));
                     }
                 }
                 bar();
@@ -617,12 +709,12 @@ void pfb_spec(const PfbMfArgs A)
                             const int k = 4 * q + kk;
                             const float2 pv = have_prev ? yp[k] : make_float2(0.0f, 0.0f);
                             float2 p;
-                            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.x), __float_as_int(y[k].re), 0x138, 0xF, 0xF, false));
-                            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.y), __float_as_int(y[k].im), 0x138, 0xF, 0xF, false));
+                            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.x), __float_as_int(re_of(y[k])), 0x138, 0xF, 0xF, false));
+                            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.y), __float_as_int(im_of(y[k])), 0x138, 0xF, 0xF, false));
 #if SNOUT_ATAN_PAIR
-                            float v = zb_discriminate_with(make_float2(y[k].re, y[k].im), p, AtanPairs{atan_p});
+                            float v = zb_discriminate_with(make_float2(re_of(y[k]), im_of(y[k])), p, AtanPairs{atan_p});
 #else
-                            float v = zb_discriminate(make_float2(y[k].re, y[k].im), p, atan_s);
+                            float v = zb_discriminate(make_float2(re_of(y[k]), im_of(y[k])), p, atan_s);
 #endif
                             if (mloc >= left) v = 0.0f;
                             if (emit) A.zb.d[(uint64_t)seg * A.segs.d_seg + (uint64_t)k * A.zb.d_stride + mg] = v;
@@ -646,7 +738,7 @@ void pfb_spec(const PfbMfArgs A)
                 } else {
                     if (mg < n_out) {
 #pragma unroll
-                        for (int k = 0; k < M; k++) A.y[(uint64_t)k * A.y_stride + mg] = make_float2(y[k].re, y[k].im);
+                        for (int k = 0; k < M; k++) A.y[(uint64_t)k * A.y_stride + mg] = make_float2(re_of(y[k]), im_of(y[k]));
                     }
                     for (int q = 0; q < PERIOD - 1; q++) bar();
                 }

@@ -15,7 +15,7 @@ for tag in "abc":
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"][:60]
-            if "pfb_channelize" not in k: continue
+            if "pfb_" not in k: continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
         for k, d in acc.items():
             for c, v in d.items():
