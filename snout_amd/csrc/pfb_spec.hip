@@ -572,6 +572,8 @@ void pfb_spec(const PfbMfArgs A)
                 // ---- Q2, Q3: 5-point DFTs over n2 per k1, epilogue per channel k = k1 + 8 k2
                 finalize();                       // the block before this one: its successor's first output times are there now
                 uint32_t m_lo = 0, m_hi = 0;
+                const bool edge = (l & 15) == 0 || (l & 15) == 15;
+                float2* const edge_slot = BT ? ((l & 15) == 0 ? &cfirst[f][par][l >> 4] : &clast[f][l >> 4]) : nullptr;
                 auto do_k1 = [&](int k1) {
                     cx b[M2], Y[M2];
     #pragma unroll
@@ -593,13 +595,11 @@ void pfb_spec(const PfbMfArgs A)
                             m_lo = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)mk, k, (int)m_lo);
                             m_hi = (uint32_t)__llvm_amdgcn_writelane((int)(uint32_t)(mk >> 32), k, (int)m_hi);
                         }
-                        const int li = l & 15;
-                        if (li == 0) {                                   // first four output times of the block
+                        // the block's first four output times (lanes 0, 16, 32, 48) and its last four (15, 31, 47, 63): one
+                        // predicated run of stores at constant offsets from the lane's slot
+                        if (edge) {
     #pragma unroll
-                            for (int k2 = 0; k2 < M2; k2++) cfirst[f][par][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
-                        } else if (li == 15) {                           // last four
-    #pragma unroll
-                            for (int k2 = 0; k2 < M2; k2++) clast[f][(k1 + M1 * k2) * 4 + (l >> 4)] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
+                            for (int k2 = 0; k2 < M2; k2++) edge_slot[(k1 + M1 * k2) * 4] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
                         }
                     } else {
                         const uint64_t mg = m0b + mloc;
