@@ -206,9 +206,9 @@ __device__ __forceinline__ void lds_barrier()
 // Wave layouts (W = waves per workgroup; waves w, w + 4, w + 8, w + 12 share a SIMD):
 //   M = 40, W = 12: waves 0-4 FIR (16 outputs per thread), 8 idle, 5-7 and 9-11 FFT   -- 3 waves per SIMD, <= 168 registers
 //   M = 40, W = 16: waves 0-9 FIR ( 8 outputs per thread), 10-15 FFT                  -- 4 waves per SIMD, <= 128 registers:
-//       the SIMDs hold 3 FIR + 1 FFT, 3 + 1, 2 + 2, 2 + 2 waves = 2216, 2216, 2384, 2384 issue cycles per tile (FIR wave 512,
-//       FFT wave 680), and a plain VALU stream reaches 81 % of its peak at four waves per SIMD against 73 % at three
-//       (tools/fmabench.hip): 2.6 against 2.8 ms per 8e8 samples.
+//       the SIMDs hold 3 FIR + 1 FFT, 3 + 1, 2 + 2, 2 + 2 waves (per tile a FIR wave issues 128 packed FMAs + 20 plain
+//       instructions, an FFT wave 113 packed + 75 plain), and a plain VALU stream reaches 81 % of its peak at four waves
+//       per SIMD against 73 % at three (tools/fmabench.hip): 2.6 against 2.8 ms per 8e8 samples (round 3).
 //   M = 16, W = 16: waves 0-3 FIR (8 outputs per thread), 4-15 FFT + 802.15.4 discriminator (a block is spread over six tile
 //       times): one FIR and three FFT waves on every SIMD.
 //   M = 16 variants (A/B builds, tools/mf_ab16.sh): SNOUT_SP16_LAYOUT = 1: 8 FIR waves (4 outputs per thread) + 8 FFT waves, a
