@@ -23,6 +23,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
@@ -454,10 +455,58 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         }
         if (n_lanes) { o[n_lanes - 1] = total; for (uint64_t j = pfrom; j < pnc; j++) { sb[total] = pb[j]; spos[total] = ppos[j]; total++; } }
         free(pb); free(ppos); free(pkey); free(cb); free(cpos); free(ckey);
-    } else
+    } else {
+    /* ANALYSIS SWITCH (tools/lane_gaps_r4.py only; never set in tests or by the product's parity runs): lane boundaries in the
+     * gaps between frames.  b[l] = the sample nearest l core (within half a core) at which the discriminator output has looked
+     * like noise for G samples (mean |d| over them above 1.2: a frame's MSK gives 0.8, noise pi/2, a neighbour's leakage more);
+     * no such sample: l core.  A lane starts its loop `warmup` samples before b[l] with the sequential filter's own state. */
+    uint64_t* bnd = NULL;
+    double* lp_seq = NULL;
+    const char* gap_env = getenv("ORACLE_ZB_EXPERIMENT_GAPS");
+    if (gap_env != NULL && atoi(gap_env) > 0 && n_lanes > 1) {
+        const uint64_t G = (uint64_t)atoi(gap_env);
+        bnd = (uint64_t*)malloc((n_lanes + 1) * 8);
+        lp_seq = (double*)malloc(n_lanes * 8);
+        uint8_t* gap = (uint8_t*)calloc(n + 1, 1);              /* gap[t]: d[t-G+1 .. t] is noise */
+        double acc = 0.0;
+        for (uint64_t t = 0; t < n; t++) {
+            acc += fabs((double)d[t]);
+            if (t >= G) acc -= fabs((double)d[t - G]);
+            gap[t] = t + 1 >= G && acc > 1.2 * (double)G;
+        }
+        bnd[0] = 0; bnd[n_lanes] = n;
+        uint64_t moved = 0;
+        for (uint64_t l = 1; l < n_lanes; l++) {
+            const uint64_t c = l * core;
+            uint64_t best = c;
+            for (uint64_t k = 0; k < core / 2; k++) {
+                if (c + k < n && gap[c + k]) { best = c + k; break; }
+                if (c >= k + 1 && c - k > bnd[l - 1] + 64 && gap[c - k]) { best = c - k; break; }
+            }
+            if (best <= bnd[l - 1] + 64) best = c > bnd[l - 1] + 64 ? c : bnd[l - 1] + 64;
+            if (best > n) best = n;
+            moved += best != c;
+            bnd[l] = best;
+        }
+        free(gap);
+        const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+        double lp = 0.0;
+        uint64_t l = 1;
+        lp_seq[0] = 0.0;
+        for (uint64_t t = 0; t < n && l < n_lanes; t++) {
+            while (l < n_lanes && (bnd[l] > warmup ? bnd[l] - warmup : 0) == t) lp_seq[l++] = lp;
+            lp = alpha * (double)d[t] + one_minus * lp;
+        }
+        while (l < n_lanes) lp_seq[l++] = lp;
+        if (getenv("ORACLE_ZB_EXPERIMENT_GAPS_VERBOSE")) fprintf(stderr, "gaps: %llu of %llu boundaries moved\n", (unsigned long long)moved, (unsigned long long)(n_lanes - 1));
+        free(lb); free(lpos); free(lkey);
+        const uint64_t cap2 = 2 * (uint64_t)core + warmup + 80;
+        lb = (uint8_t*)malloc(cap2); lpos = (uint64_t*)malloc(cap2 * 8); lkey = (uint64_t*)malloc(cap2 * 8);
+    }
     for (uint64_t l = 0; l < n_lanes; l++) {
-        const uint64_t cs = l * core, ce = cs + core;
-        const uint64_t nc = mm_lane(d, n, cs, core, warmup, lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
+        const uint64_t cs = bnd ? bnd[l] : l * core, ce = bnd ? bnd[l + 1] : cs + core;
+        if (bnd && ce <= cs) { o[l] = total; seam[l] = 0; continue; }
+        const uint64_t nc = mm_lane(d, n, cs, ce - cs, warmup, bnd ? lp_seq[l] : lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
         uint64_t f = 0;
         seam[l] = l ? 0xFFFFFFFFFFFFull : 0;                        /* no comparison made: nothing verified */
         if (l > 0) {
@@ -489,6 +538,8 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         prev_nc = nc;
         prev_hist = 0;                                              /* last 64 chips of the lane, MSB first */
         for (uint64_t j = (nc >= 64 ? nc - 64 : 0); j < nc; j++) prev_hist = (prev_hist << 1) | lb[j];
+    }
+    free(bnd); free(lp_seq);
     }
     o[n_lanes] = total;
     if (g_dbg_bits) {
