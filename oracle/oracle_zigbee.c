@@ -263,6 +263,10 @@ typedef struct {
     uint64_t t_last;         /* key of the last chip (valid if n_chips) */
 } lane_chips_t;
 
+/* ANALYSIS SWITCH ORACLE_ZB_EXPERIMENT_TWOSTART (tools/lane_gaps_r4.py only): samples by which the next mm_lane call starts its
+ * loop later (0 or 1); per thread, channel_lanes runs one channel per thread */
+static _Thread_local int g_exp_start_shift = 0;
+
 /* a5 + a6 of one lane; appends (bit, pos) of ALL its chips to bits/pos/key (capacity ensured by the
  * caller: (core + warmup) chips at most).  soft_z / soft_chips: optional taps. */
 static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t core_len,
@@ -280,6 +284,7 @@ static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_
     uint64_t ii = s0, z_next = s0, chips = 0;
     float warm_gain = 1.0f;
     { const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_WARMGAIN") : NULL; if (e) warm_gain = (float)atof(e); }
+    if (s0 && g_exp_start_shift) ii += (uint64_t)g_exp_start_shift;     /* ORACLE_ZB_EXPERIMENT_TWOSTART, see channel_lanes */
     {   /* ANALYSIS SWITCH (tools/lane_residual_r4.py only): start the lane's loop this many quarter samples later */
         const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_PHASE0") : NULL;
         if (e) { const int q = atoi(e); ii += (uint64_t)(q / 4); mu = 0.5f + 0.25f * (float)(q % 4); if (mu >= 1.0f) { mu -= 1.0f; ii++; } }
@@ -506,7 +511,24 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
     for (uint64_t l = 0; l < n_lanes; l++) {
         const uint64_t cs = bnd ? bnd[l] : l * core, ce = bnd ? bnd[l + 1] : cs + core;
         if (bnd && ce <= cs) { o[l] = total; seam[l] = 0; continue; }
+        /* ANALYSIS SWITCH: the timing loop of a lane that starts inside a frame can hang at the half-chip point for hundreds of
+         * chips (Mueller & Mueller's hang-up).  Run the warm-up from two starts one sample (half a chip) apart and keep the one
+         * with the wider eye: sum |interpolated sample| over the last E chips before the core. */
+        if (l > 0 && getenv("ORACLE_ZB_EXPERIMENT_TWOSTART") != NULL) {
+            const uint64_t Ew = (uint64_t)atoi(getenv("ORACLE_ZB_EXPERIMENT_TWOSTART"));
+            float* sc = (float*)malloc((warmup + 64) * sizeof(float));
+            double eye[2] = {0.0, 0.0};
+            for (int c = 0; c < 2; c++) {
+                g_exp_start_shift = c;
+                const uint64_t s0w = cs > warmup ? cs - warmup : 0;
+                const uint64_t k = mm_lane(d, n, s0w, cs - s0w, 0, bnd ? lp_seq[l] : lp_in[l], NULL, NULL, NULL, NULL, sc, warmup + 64);
+                for (uint64_t j = k > Ew ? k - Ew : 0; j < k; j++) eye[c] += fabs((double)sc[j]);
+            }
+            free(sc);
+            g_exp_start_shift = eye[1] > eye[0] ? 1 : 0;
+        }
         const uint64_t nc = mm_lane(d, n, cs, ce - cs, warmup, bnd ? lp_seq[l] : lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
+        g_exp_start_shift = 0;
         uint64_t f = 0;
         seam[l] = l ? 0xFFFFFFFFFFFFull : 0;                        /* no comparison made: nothing verified */
         if (l > 0) {

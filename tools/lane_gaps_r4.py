@@ -27,16 +27,23 @@ def missing(A, B):
     return sum(1 for c, b, s in A if not any(abs(s - u) <= 8 for u in d.get((c, b), [])))
 
 
-def run(x, core, warm, gaps):
-    os.environ.pop("ORACLE_ZB_EXPERIMENT_GAPS", None)
+def run(x, core, warm, gaps, two=0):
+    for k in ("ORACLE_ZB_EXPERIMENT_GAPS", "ORACLE_ZB_EXPERIMENT_TWOSTART"):
+        os.environ.pop(k, None)
     if gaps:
         os.environ["ORACLE_ZB_EXPERIMENT_GAPS"] = str(gaps)
+    if two:
+        os.environ["ORACLE_ZB_EXPERIMENT_TWOSTART"] = str(two)
     r = oracle_py.wideband_segment(x, proto=1, core=core, warmup=warm)
-    os.environ.pop("ORACLE_ZB_EXPERIMENT_GAPS", None)
+    for k in ("ORACLE_ZB_EXPERIMENT_GAPS", "ORACLE_ZB_EXPERIMENT_TWOSTART"):
+        os.environ.pop(k, None)
     return key(r[r["crc_ok"] == 1])
 
 
-cases = [(4096, 512, 0), (4096, 512, 96), (8192, 512, 0), (8192, 512, 96), (16384, 512, 0), (16384, 512, 96), (16384, 128, 96)]
+cases = [(2048, 512, 0, 0), (2048, 512, 0, 64), (2048, 512, 0, 128), (4096, 512, 0, 0), (4096, 512, 0, 32), (4096, 512, 0, 64), (4096, 512, 0, 128), (4096, 512, 0, 240),
+         (4096, 256, 0, 64), (4096, 1024, 0, 128), (8192, 512, 0, 0), (8192, 512, 0, 128)]
+if os.environ.get("GAPS"):
+    cases = [(4096, 512, 0, 0), (4096, 512, 96, 0), (8192, 512, 0, 0), (8192, 512, 96, 0), (16384, 512, 0, 0), (16384, 512, 96, 0), (16384, 128, 96, 0)]
 tot = collections.Counter()
 for sg in range(n_seg):
     rng = np.random.default_rng(100 + sg)
@@ -51,4 +58,5 @@ for sg in range(n_seg):
 print(which, "capture: FCS-ok frames of one sequential lane per channel:", tot["one"])
 print("| core / warm-up | boundaries | lost vs one lane | extra |\n|---|---|---|---|")
 for c in cases:
-    print(f"| {c[0]} / {c[1]} | {'fixed grid' if not c[2] else 'in gaps (noise for %d samples)' % c[2]} | {tot[(c, 'lost')]} ({100.0 * tot[(c, 'lost')] / tot['one']:.2f} %) | {tot[(c, 'extra')]} |")
+    how = ('fixed grid' if not c[2] else 'in gaps (noise for %d samples)' % c[2]) + ('' if not c[3] else ', two starts, eye over %d chips' % c[3])
+    print(f"| {c[0]} / {c[1]} | {how} | {tot[(c, 'lost')]} ({100.0 * tot[(c, 'lost')] / tot['one']:.2f} %) | {tot[(c, 'extra')]} |")
