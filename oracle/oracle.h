@@ -46,6 +46,9 @@ int      oracle_pfb(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t 
 /* the same sums in the term order of the experimental matrix-pipe FIR (snout_amd/csrc/pfb_mfma.hip); differs from
  * oracle_pfb only for non-finite samples and results that are zero */
 int oracle_pfb_block_order(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t y_stride);
+/* M = 40: 1 = the Cooley-Tukey FFT with twiddles that rounds 1-3 specified (what the A/B partners pfb.hip / pfb_mfma.hip compute),
+ * 0 = the shipped prime-factor form; process-wide, set around a call by the tests of those two kernels only */
+void oracle_pfb_legacy_fft(int on);
 uint32_t oracle_btle_bin_channel(uint32_t bin);
 uint32_t oracle_zigbee_bin_channel(uint32_t bin);
 int      oracle_wideband_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t proto,

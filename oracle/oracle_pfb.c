@@ -14,10 +14,17 @@
  *   y_k[m] = (-1)^{k m} X_m[k]                                 (D = M/2 phase rotation)
  * for m = 0 .. n_out-1, n_out = (n - L)/D + 1.  y_k is channel k (centre k fs/M) at 2 fs/M.
  *
- * FFT: n = M2 n1 + n2, k = k1 + M1 k2;  M = 40: M1 = 8, M2 = 5;  M = 16: M1 = M2 = 4.
+ * FFT, M = 16 (M1 = M2 = 4, Cooley-Tukey): n = M2 n1 + n2, k = k1 + M1 k2;
  *   A[n2][k1] = DFT_M1 over n1 (radix-2 DIT butterflies, exact +-1/+-i, sqrt(1/2) as one f32)
  *   B[n2][k1] = A[n2][k1] W_M^{n2 k1}        re = fmaf(a,c,-(b d)), im = fmaf(a,d,b c)
- *   X[k1 + M1 k2] = DFT_M2 over n2           M2 = 5: real-factor form (dft5 below); M2 = 4: butterflies
+ *   X[k1 + M1 k2] = DFT_M2 over n2           butterflies
+ * FFT, M = 40 (8 x 5, coprime: Good-Thomas prime-factor mapping, no twiddle factors -- since round 4):
+ *   n = (5 n1 + 8 n2) mod 40,  k = (25 k1 + 16 k2) mod 40  (k = k1 mod 8, k = k2 mod 5), so n k = 5 n1 k1 + 8 n2 k2 mod 40 and
+ *   A[n2][k1] = DFT_8 over n1 of u[(5 n1 + 8 n2) mod 40]    (dft8 below)
+ *   X[(25 k1 + 16 k2) mod 40] = DFT_5 over n2 of A[n2][k1]  (real-factor form, dft5 below)
+ *   (Rounds 1-3 specified the Cooley-Tukey form with the 28 twiddle products W_40^{n2 k1}; the two are the same DFT and differ
+ *   in the last bits.  The Cooley-Tukey form stays available -- oracle_pfb_legacy_fft() -- as the specification of the two
+ *   kernels kept as A/B partners in libsnout_rx_ab.so, pfb.hip and pfb_mfma.hip.)
  */
 #include <math.h>
 #include <stdint.h>
@@ -82,7 +89,28 @@ static void dft5(const cf b[5], cf X[5])
     X[3].re = a2.re - s2.im; X[3].im = a2.im + s2.re;
 }
 
+/* the shipped specification: prime-factor 8 x 5 */
 static void fft40(const cf* u, cf* X)
+{
+    cf A[5][8];
+    for (int n2 = 0; n2 < 5; n2++) {
+        cf a[8];
+        for (int n1 = 0; n1 < 8; n1++) a[n1] = u[(5 * n1 + 8 * n2) % 40];
+        dft8(a, A[n2]);
+    }
+    for (int k1 = 0; k1 < 8; k1++) {
+        cf b[5], Y[5];
+        for (int n2 = 0; n2 < 5; n2++) b[n2] = A[n2][k1];
+        dft5(b, Y);
+        for (int k2 = 0; k2 < 5; k2++) X[(25 * k1 + 16 * k2) % 40] = Y[k2];
+    }
+}
+
+/* rounds 1-3: Cooley-Tukey 8 x 5 with twiddles (the A/B partners' specification) */
+static int g_legacy_fft = 0;
+void oracle_pfb_legacy_fft(int on) { g_legacy_fft = on != 0; }
+
+static void fft40_ct(const cf* u, cf* X)
 {
     cf B[5][8];
     for (int n2 = 0; n2 < 5; n2++) {
@@ -193,7 +221,7 @@ static int pfb_impl(const float* iq, uint64_t n, uint32_t M, float* y, uint64_t 
             if (M == 40 && block_order && (nonfinite || ar == 0.0f || ai == 0.0f)) fir40_block_order(iq, n, (uint64_t)m, r, h, &ar, &ai);
             u[r].re = ar; u[r].im = ai;
         }
-        if (M == 40) fft40(u, X); else fft16(u, X);
+        if (M == 40) { if (g_legacy_fft) fft40_ct(u, X); else fft40(u, X); } else fft16(u, X);
         for (uint32_t k = 0; k < M; k++) {
             cf v = X[k];
             if (k & (uint32_t)m & 1u) { v.re = -v.re; v.im = -v.im; }

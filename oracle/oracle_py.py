@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
         _lib.oracle_pfb.restype = C.c_int
         _lib.oracle_pfb_block_order.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint64]
         _lib.oracle_pfb_block_order.restype = C.c_int
+        _lib.oracle_pfb_legacy_fft.argtypes = [C.c_int]
+        _lib.oracle_pfb_legacy_fft.restype = None
         _lib.oracle_btle_bin_channel.argtypes = [C.c_uint32]
         _lib.oracle_btle_bin_channel.restype = C.c_uint32
         _lib.oracle_zigbee_bin_channel.argtypes = [C.c_uint32]
@@ -251,14 +253,20 @@ def pfb_proto(M: int) -> np.ndarray:
     return np.array(lib().oracle_pfb_proto(M)[:M * 16], dtype=np.float32)
 
 
-def pfb(iq: np.ndarray, M: int, block_order: bool = False) -> np.ndarray:
-    """-> complex64 [M, n_out].  block_order: the term order of the experimental matrix-pipe FIR (SNOUT_PFB_IMPL=mfma)."""
+def pfb(iq: np.ndarray, M: int, block_order: bool = False, legacy_fft: bool = False) -> np.ndarray:
+    """-> complex64 [M, n_out].  block_order: the term order of the experimental matrix-pipe FIR (SNOUT_PFB_IMPL=mfma).
+    legacy_fft (M = 40): the Cooley-Tukey FFT with twiddles of rounds 1-3 instead of the shipped prime-factor form -- the
+    specification of the A/B partners pfb.hip / pfb_mfma.hip (libsnout_rx_ab.so) only."""
     a = _f32(iq)
     n = a.size // 2
     no = pfb_nout(n, M)
     y = np.zeros((M, max(no, 1) * 2), dtype=np.float32)
     fn = lib().oracle_pfb_block_order if block_order else lib().oracle_pfb
-    rc = fn(_p(a, C.c_float), n, M, _p(y, C.c_float), max(no, 1))
+    lib().oracle_pfb_legacy_fft(1 if legacy_fft else 0)
+    try:
+        rc = fn(_p(a, C.c_float), n, M, _p(y, C.c_float), max(no, 1))
+    finally:
+        lib().oracle_pfb_legacy_fft(0)
     assert rc == 0
     return y.view(np.complex64)[:, :no]
 

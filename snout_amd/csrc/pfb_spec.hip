@@ -15,7 +15,7 @@
 //               pfb.hip, 128 output times per tile, FIR outputs double-buffered in LDS; the same threads fetch the input
 //               two tiles ahead (two register sets) and stage it behind their FIR.
 //   FFT waves (M = 40: waves 10-15, M = 16: 4-15): a thread owns one output time of a 64-time block: 20 ds_read_b128 of
-//               its row, then the whole 8 x 5 (4 x 4) FFT of oracle_pfb.c in registers (no LDS round trip, no barrier
+//               its row, then the whole 8 x 5 (prime-factor, no twiddles) / 4 x 4 FFT of oracle_pfb.c in registers (no LDS round trip, no barrier
 //               inside) and the epilogue on its results; a block is spread over three (six) tile times, barriers inside
 //               the straight-line code, so six (twelve) blocks are always in flight.
 //               BTLE: lane = 16 (m mod 4) + (m / 4 mod 16): y[m+4] is the next lane of the DPP row, and the 64
@@ -537,6 +537,8 @@ void pfb_spec(const PfbMfArgs A)
                 }
             };
 
+            // channel of (k1, k2) in the prime-factor output map: k = k1 mod 8, k = k2 mod 5
+            auto kch = [](int k1, int k2) { return (25 * k1 + 16 * k2) % 40; };
             int kblk = 0;
             for (int j = j0; j < NTL; j += 3, kblk++) {
                 const uint32_t tile = t_lo + (uint32_t)j;
@@ -544,7 +546,7 @@ void pfb_spec(const PfbMfArgs A)
                 const bool emit = tile < t_end;                          // the tile behind the range only supplies its first four times
                 const bool need = emit || half == 0;
                 const int par = kblk & 1;
-                // ---- Q1: the row, 8-point DFTs over n1 and the twiddles W_40^{n2 k1}
+                // ---- Q1: the row and the 8-point DFTs over n1 (inputs in the prime-factor order (5 n1 + 8 n2) mod 40)
                 cx Bv[M2][M1];
                 if (need) {
                     const float4* rowp = reinterpret_cast<const float4*>(&us[j & 1][(64 * half + l) * ROW]);
@@ -559,17 +561,16 @@ void pfb_spec(const PfbMfArgs A)
                     for (int n2 = 0; n2 < M2; n2++) {
                         cx a[M1], X[M1];
     #pragma unroll
-                        for (int n1 = 0; n1 < M1; n1++) a[n1] = u[M2 * n1 + n2];
+                        for (int n1 = 0; n1 < M1; n1++) a[n1] = u[(M2 * n1 + M1 * n2) % M];    // prime-factor input map
                         dft8(a, X);
     #pragma unroll
                         for (int k1 = 0; k1 < M1; k1++) {
-                            const int jj = (n2 * k1) % M;
-                            Bv[n2][k1] = jj == 0 ? X[k1] : mul_tw(X[k1], tw[2 * jj], tw[2 * jj + 1]);    // literals
+                            Bv[n2][k1] = X[k1];                                                   // 8 and 5 are coprime: no twiddles
                         }
                     }
                 }
                 bar();
-                // ---- Q2, Q3: 5-point DFTs over n2 per k1, epilogue per channel k = k1 + 8 k2
+                // ---- Q2, Q3: 5-point DFTs over n2 per k1, epilogue per channel k = (25 k1 + 16 k2) mod 40
                 finalize();                       // the block before this one: its successor's first output times are there now
                 uint32_t m_lo = 0, m_hi = 0;
                 const bool edge = (l & 15) == 0 || (l & 15) == 15;
@@ -588,7 +589,7 @@ void pfb_spec(const PfbMfArgs A)
                         // factor (-1)^{km} is the same for m and m + 4 and cancels in both products.
     #pragma unroll
                         for (int k2 = 0; k2 < M2; k2++) {
-                            const int k = k1 + M1 * k2;
+                            const int k = kch(k1, k2);
                             const float qn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(im_of(Y[k2])), 0x101, 0xF, 0xF, true));
                             const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(re_of(Y[k2])), 0x101, 0xF, 0xF, true));
                             const uint64_t mk = __builtin_amdgcn_ballot_w64((re_of(Y[k2]) * qn) > (in * im_of(Y[k2])));
@@ -599,14 +600,14 @@ void pfb_spec(const PfbMfArgs A)
                         // predicated run of stores at constant offsets from the lane's slot
                         if (edge) {
     #pragma unroll
-                            for (int k2 = 0; k2 < M2; k2++) edge_slot[(k1 + M1 * k2) * 4] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
+                            for (int k2 = 0; k2 < M2; k2++) edge_slot[kch(k1, k2) * 4] = make_float2(re_of(Y[k2]), im_of(Y[k2]));
                         }
                     } else {
                         const uint64_t mg = m0b + mloc;
                         if (mg < n_out) {
     #pragma unroll
                             for (int k2 = 0; k2 < M2; k2++) {
-                                const int k = k1 + M1 * k2;
+                                const int k = kch(k1, k2);
                                 float vr = re_of(Y[k2]), vi = im_of(Y[k2]);
                                 if ((k & 1) && (mg & 1)) { vr = -vr; vi = -vi; }
                                 A.y[(uint64_t)k * A.y_stride + mg] = make_float2(vr, vi);

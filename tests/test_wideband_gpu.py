@@ -58,12 +58,12 @@ sys.path.insert(0, %(root)r)
 from oracle import oracle_py
 from snout_amd.rx import SnoutRx
 from snout_amd._ffi import STAGE_CHAN_IQ
-M, proto, block = %(M)d, %(proto)d, %(block)r
+M, proto, block, legacy = %(M)d, %(proto)d, %(block)r, %(legacy)r
 n = M * 16 + (M // 2) * 5000 + 3
 rng = np.random.default_rng(7)
 x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
 x[n // 2] = np.nan
-want = oracle_py.pfb(x, M, block_order=block)
+want = oracle_py.pfb(x, M, block_order=block, legacy_fft=legacy)
 with SnoutRx(proto=proto, n_channels=M, keep_channel_iq=True) as rx:
     rx.process(x)
     for slot in (0, 1, M // 2, M - 1):
@@ -76,18 +76,20 @@ print("equal")
 '''
 
 
-@pytest.mark.parametrize("impl,M,proto,block", [("valu", 40, 0, False), ("valu", 16, 1, False), ("spec12", 40, 0, False),
-                                                 ("mfma", 40, 0, True)])
-def test_the_kept_ab_partners_of_the_channelizer_are_bit_exact_too(impl, M, proto, block):
+@pytest.mark.parametrize("impl,M,proto,block,legacy", [("valu", 40, 0, False, True), ("valu", 16, 1, False, False),
+                                                        ("spec12", 40, 0, False, False), ("mfma", 40, 0, True, True)])
+def test_the_kept_ab_partners_of_the_channelizer_are_bit_exact_too(impl, M, proto, block, legacy):
     """In `libsnout_rx_ab.so` (`make -C snout_amd/csrc ab`: the product sources plus `pfb.hip` and `pfb_mfma.hip`)
     `SNOUT_PFB_IMPL` (read when a handle is created) selects the kernels kept beside the shipped `pfb_spec`: round 2's
     `pfb_channelize` (valu), the 12-wave layout (spec12) -- both the plain fmaf chain of `oracle_pfb` -- and the matrix-pipe
     FIR (mfma) = `oracle_pfb_block_order` (banded-Toeplitz blocks of `v_mfma_f32_16x16x4_f32`; the snippet's input carries a
-    NaN, which is where the two orders differ), bit for bit."""
+    NaN, which is where the two orders differ), bit for bit.  `pfb.hip` and `pfb_mfma.hip` keep the M = 40 FFT that rounds 1-3
+    specified (Cooley-Tukey 8 x 5 with twiddles: `legacy_fft`); the shipped kernel and its 12-wave layout run the prime-factor
+    form that `oracle_pfb` specifies since round 4."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SNOUT_PFB_IMPL=impl, SNOUT_RX_LIB=os.path.join(root, "snout_amd", "lib", "libsnout_rx_ab.so"))
-    r = subprocess.run([sys.executable, "-c", _IMPL_SNIPPET % dict(root=root, M=M, proto=proto, block=block)],
+    r = subprocess.run([sys.executable, "-c", _IMPL_SNIPPET % dict(root=root, M=M, proto=proto, block=block, legacy=legacy)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("equal"), r.stderr[-2000:]
 
