@@ -289,7 +289,7 @@ void pfb_spec(const PfbMfArgs A)
     const int NTL = (int)(t_hi - t_lo);
     const int IT = NTL + PERIOD + 1;                     // barriers after the first one (pipeline drain included)
 
-    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;      // w in an SGPR: the roles' branches and the FFT waves' block loops are scalar
     if constexpr (ZB) {
         if (SNOUT_ATAN_PAIR) { for (int i = t; i < 256; i += 64 * W) atan_p[i] = make_float2(A.zb.atan_tab[i], A.zb.atan_tab[i + 1]); }
         else { for (int i = t; i < 257; i += 64 * W) atan_s[i] = A.zb.atan_tab[i]; }
@@ -543,8 +543,9 @@ void pfb_spec(const PfbMfArgs A)
             for (int j = j0; j < NTL; j += 3, kblk++) {
                 const uint32_t tile = t_lo + (uint32_t)j;
                 const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)half;
-                const bool emit = tile < t_end;                          // the tile behind the range only supplies its first four times
-                const bool need = emit || half == 0;
+                // (as scalars by force: kept as lane masks the two flags cost a v_cndmask / v_cmp pair at every use)
+                const bool emit = __builtin_amdgcn_readfirstlane((int)(tile < t_end)) != 0;   // the tile behind the range only supplies its first four times
+                const bool need = __builtin_amdgcn_readfirstlane((int)(emit || half == 0)) != 0;
                 const int par = kblk & 1;
                 // ---- Q1: the row and the 8-point DFTs over n1 (inputs in the prime-factor order (5 n1 + 8 n2) mod 40)
                 cx Bv[M2][M1];

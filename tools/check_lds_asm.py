@@ -37,14 +37,23 @@ def check(text: str):
     pending = []            # [(registers an LDS read will fill, line number)] of every outstanding LDS operation, in issue order
     smem = 0
     n_reads = 0
+    saved = {}              # label -> the pending list an unconditional branch to it carried
+    unreachable = False     # behind an s_branch, up to the next label
     for ln, line in enumerate(text.splitlines(), 1):
         s = line.strip()
-        if not s or s.startswith((";", ".", "//")):
+        is_label = bool(re.match(r"^[\w.$]+:\s*(;.*)?$", s))
+        if not s or (s.startswith((";", ".", "//")) and not (is_label and s.startswith(".L"))):
             continue
-        if s.endswith(":") or re.match(r"^[\w.$]+:\s*(;.*)?$", s):
+        if is_label:
             lab = s.split(":")[0]
             if lab.startswith("_Z") or not lab.startswith((".L", "L")):
-                kernel, pending, smem = lab, [], 0
+                kernel, pending, smem, saved, unreachable = lab, [], 0, {}, False
+            elif unreachable:
+                pending, unreachable = list(saved.get(lab, [])), False
+            elif lab in saved:
+                pending = pending + [e for e in saved[lab] if e not in pending]     # either way in: the union
+            continue
+        if unreachable:
             continue
         parts = s.split(None, 1)
         op = parts[0]
@@ -60,9 +69,14 @@ def check(text: str):
             continue
         if op in ("s_endpgm",):
             pending, smem = [], 0
+            unreachable = True
             continue
-        if op.startswith(("s_load_", "s_buffer_load_")):
-            smem += 1
+        if op == "s_branch" and ops:
+            saved[ops[0]] = saved.get(ops[0], []) + [e for e in pending if e not in saved.get(ops[0], [])]
+            unreachable = True
+            continue
+        if op.startswith(("s_load_", "s_buffer_load_", "s_store_", "s_buffer_store_", "s_dcache_")):
+            smem += 1                   # scalar memory operations share the counter and complete out of order
             continue
         is_lds_read = op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append", "ds_ordered")) or \
             (op.startswith("ds_") and "_rtn" in op)
