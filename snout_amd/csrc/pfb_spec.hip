@@ -289,7 +289,9 @@ void pfb_spec(const PfbMfArgs A)
     const int NTL = (int)(t_hi - t_lo);
     const int IT = NTL + PERIOD + 1;                     // barriers after the first one (pipeline drain included)
 
-    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;      // w in an SGPR: the roles' branches and the FFT waves' block loops are scalar
+    // M = 40: w in an SGPR -- the roles' branches and the FFT waves' block loops become scalar branches (- 1.5 %; at M = 16 the
+    // same costs 1 %: profiles/r4_spec_ab.txt)
+    const int t = threadIdx.x, w = M == 40 ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6), l = t & 63;
     if constexpr (ZB) {
         if (SNOUT_ATAN_PAIR) { for (int i = t; i < 256; i += 64 * W) atan_p[i] = make_float2(A.zb.atan_tab[i], A.zb.atan_tab[i + 1]); }
         else { for (int i = t; i < 257; i += 64 * W) atan_s[i] = A.zb.atan_tab[i]; }
