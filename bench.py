@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -332,11 +333,16 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         run_steps(warmup)
     drain()
     fence()
+    # the interpreter's cyclic collector stays out of the timed steps (a generation-2 pass is several ms of host time: two of
+    # the three queued steps' worth)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     run_steps(steps)
     drain()                 # every step's records are on rank 0 before the clock stops
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -548,10 +554,13 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     fence()
     if trace is not None:
         del trace[:]
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     run_steps(steps)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if trace is not None and rank == 0:
         import collections
         agg, cnt = collections.Counter(), collections.Counter()
