@@ -60,3 +60,22 @@ def test_block_order_entry_differs_only_where_a_structural_zero_meets_a_non_fini
     na, nb = np.isnan(a.view(np.float32)), np.isnan(b.view(np.float32))
     assert na.any() and (nb | ~na).all() and nb.sum() > na.sum()          # the plain chain's NaNs are a strict subset
     assert np.array_equal(a.view(np.uint32)[~nb], b.view(np.uint32)[~nb])
+
+
+def test_the_prime_factor_fft_and_the_legacy_cooley_tukey_entry(oracle):
+    """Since round 4 the M = 40 DFT is specified as a prime-factor 8 x 5 decomposition (no twiddle products); the
+    Cooley-Tukey form of rounds 1-3 stays behind `legacy_fft` as the specification of the A/B partner kernels.  Both are the
+    same DFT: they differ from each other and from a float64 DFT in the last bits only, the switch is per call (it does not
+    stick), and M = 16 has one form."""
+    rng = np.random.default_rng(11)
+    n = 40 * 16 + 20 * 500 + 3
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    want = _direct(x, oracle.pfb_proto(40).astype(np.float64), 40)
+    scale = np.abs(want).max()
+    pfa, ct, again = oracle.pfb(x, 40), oracle.pfb(x, 40, legacy_fft=True), oracle.pfb(x, 40)
+    assert np.array_equal(pfa.view(np.uint32), again.view(np.uint32))
+    assert not np.array_equal(pfa.view(np.uint32), ct.view(np.uint32))
+    assert np.max(np.abs(pfa - ct)) <= 5e-7 * scale
+    assert np.max(np.abs(pfa - want)) <= 2e-6 * scale and np.max(np.abs(ct - want)) <= 2e-6 * scale
+    x16 = x[:16 * 16 + 8 * 300]
+    assert np.array_equal(oracle.pfb(x16, 16).view(np.uint32), oracle.pfb(x16, 16, legacy_fft=True).view(np.uint32))
