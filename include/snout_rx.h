@@ -116,6 +116,10 @@ typedef struct snout_rx_cfg {
  * the hand-over differently -- the frame's chips depend on which loop is asked, so the reference's one sequential
  * loop may have decided this frame differently too.  Never set with one lane per channel. */
 #define SNOUT_PKT_ZB_SEAM_DISAGREED 0x04u
+/* An 802.15.4 frame that the lanes' sink gave up (or finished with a bad FCS) behind a hand-over and that was received
+ * again by ONE timing loop from the lane that found its SFD to its last chip, as the reference's sequential loop
+ * receives every frame (frame repair).  Never set with one lane per channel. */
+#define SNOUT_PKT_ZB_REPAIRED 0x08u
 
 /* One decoded packet. Fixed 160 bytes so records can be gathered across ranks as flat bytes. */
 typedef struct snout_pkt {

@@ -107,6 +107,7 @@ typedef struct {
     unsigned lqi, lqi_cnt;
     uint64_t trigger;   /* input sample index at which the first preamble symbol matched */
     uint64_t sync;      /* `at` of the chip that completed the SFD (state 0 -> 1) */
+    int chip_err;       /* the last return to search came from a symbol without a chip word within the threshold */
     uint8_t pkt[128];
 } lane_t;
 
@@ -114,7 +115,7 @@ static inline unsigned popc(uint32_t v) { return (unsigned)__builtin_popcount(v)
 
 static void enter_search(lane_t* s)
 {
-    s->state = 0; s->shift = 0; s->preamble_cnt = 0; s->chip_cnt = 0; s->packet_byte = 0;
+    s->state = 0; s->shift = 0; s->preamble_cnt = 0; s->chip_cnt = 0; s->packet_byte = 0; s->chip_err = 0;
 }
 
 static int decode_chips(lane_t* s, unsigned threshold)
@@ -181,7 +182,7 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
         if (s->chip_cnt == 32) {
             s->chip_cnt = 0;
             int c = decode_chips(s, th);
-            if (c == 0xFF) { enter_search(s); return 0; }
+            if (c == 0xFF) { enter_search(s); s->chip_err = 1; return 0; }
             if (s->byte_index == 0) s->packet_byte = c; else s->packet_byte |= c << 4;
             s->byte_index++;
             if (s->byte_index % 2 == 0) {
@@ -199,7 +200,7 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
         s->chip_cnt = (s->chip_cnt + 1) % 32;
         if (s->chip_cnt == 0) {
             int c = decode_chips(s, th);
-            if (c == 0xFF) { enter_search(s); return 0; }
+            if (c == 0xFF) { enter_search(s); s->chip_err = 1; return 0; }
             if (s->byte_index == 0) s->packet_byte = c; else s->packet_byte |= c << 4;
             s->byte_index++;
             if (s->byte_index % 2 == 0) {
@@ -257,68 +258,112 @@ static int sink_chip(lane_t* s, float chip, uint64_t at, unsigned th)
  */
 #define ORACLE_ZB_SINK_WARM 512u
 
+/*
+ * Frame repair (round 5; what makes the lanes' frames those of the ONE sequential loop on dense traffic).
+ * At two samples per chip the M&M loop has two stable lock points one sample (half a chip) apart.  A loop that meets a
+ * frame at its preamble takes the one that decodes and keeps it to the end of the frame; a lane that starts inside a
+ * payload takes whichever is nearer to its starting phase, and when that is the other one the stitched stream slips
+ * half a chip at the seam: the sink gives the frame up at the first symbol with >= threshold chip errors
+ * (profiles/r4_lane_residual.md: 4-7 % of the sequential receiver's frames on cfg #4's traffic, all of them frames
+ * with a seam behind their SFD).  The sequential loop has no seams.  So a frame that a lane's sink
+ *   - has synchronised to (SFD found at a chip the lane owns) and then
+ *   - gives up at a symbol (state 1 or 2, no chip word within the threshold), or completes with a bad FCS,
+ *   - at a chip that a LATER lane owns (a seam lies between the SFD and that chip),
+ * is received again the way the sequential receiver receives it -- by the loop that met its preamble going ON instead
+ * of handing over: lane l's loop continues from its state at its core end (every z the value lane l's own filter
+ * recurrence gives), lane l's sink from its state at the seam (taken when it crosses the next lane's first owned chip
+ * while busy, state 1 or 2), over the samples of lane l + 1.  Where lane l + 2 takes over -- from half a chip before the
+ * window start of its first owned chip -- the sink returns to the stitched stream (bounded work: one lane's samples; a
+ * second wrong hand-over inside one frame is rare and loses the frame).  What that run decodes replaces what the lanes
+ * decoded: a record if the frame completes (SNOUT_PKT_ZB_REPAIRED), nothing if it is given up again -- then the loop that
+ * met the preamble loses it as well.  For the sequential rule (Resolve) the repaired frame occupies the stream chips
+ * from the trigger found before to the chip it ends at; it takes its place in the lane's records where the lane's sink
+ * stopped.
+ * One lane (core >= n) has no seams and repairs nothing: the reference's receiver itself.
+ */
+
+static int g_zb_repair = 1;
+/* test / analysis knob: 0 = the lanes alone (rounds 1-4), 1 = with frame repair (the product's default) */
+void oracle_zb_set_repair(int on) { g_zb_repair = on; }
+
 typedef struct {
     uint64_t n_chips;        /* chips produced by the lane's M&M */
     uint64_t first_owned;    /* index of the first owned chip (<= n_chips) */
     uint64_t t_last;         /* key of the last chip (valid if n_chips) */
 } lane_chips_t;
 
-/* ANALYSIS SWITCH ORACLE_ZB_EXPERIMENT_TWOSTART (tools/lane_gaps_r4.py only): samples by which the next mm_lane call starts its
- * loop later (0 or 1); per thread, channel_lanes runs one channel per thread */
-static _Thread_local int g_exp_start_shift = 0;
+/* The M&M recurrence of one loop: state + one step.  z holds the DC-removed samples in a ring of 16. */
+typedef struct {
+    double lp;
+    float mu, omega, last;
+    float ring[16];
+    uint64_t ii, z_next;
+} mm_t;
+
+static void mm_start(mm_t* m, uint64_t iir_from, double lp_init, uint64_t ii)
+{
+    memset(m, 0, sizeof(*m));
+    m->lp = lp_init; m->mu = 0.5f; m->omega = 2.0f; m->last = 0.0f;
+    m->ii = ii; m->z_next = iir_from;
+}
+
+/* one chip: the interpolated sample at (ii, mu); advances the loop.  Caller guarantees ii + 8 <= n. */
+static inline float mm_step(mm_t* m, const float* d, uint64_t n, int* imu_out, float* soft_z, uint64_t soft_base,
+                            uint64_t soft_cap)
+{
+    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+    const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
+    const float omega_lim = omega_mid * 0.0002f;
+    while (m->z_next < m->ii + 8 && m->z_next < n) {
+        const float x = d[m->z_next];
+        m->lp = alpha * (double)x + one_minus * m->lp;
+        const float z = x - (float)m->lp;
+        m->ring[m->z_next & 15] = z;
+        if (soft_z && m->z_next - soft_base < soft_cap) soft_z[m->z_next - soft_base] = z;
+        m->z_next++;
+    }
+    float win[8];
+    for (int k = 0; k < 8; k++) win[k] = m->ring[(m->ii + k) & 15];
+    const int imu = (int)rintf(m->mu * 128.0f);
+    float acc = 0.0f;
+    for (int k = 0; k < 8; k++) acc = fmaf(kMmseTaps[imu][k], win[7 - k], acc);
+    const float o = acc;
+    *imu_out = imu;
+    const float mm = (m->last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * m->last;
+    m->last = o;
+    m->omega = m->omega + gain_omega * mm;
+    {
+        const float x = m->omega - omega_mid;
+        const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+        m->omega = omega_mid + c;
+    }
+    m->mu = m->mu + m->omega + gain_mu * mm;
+    const float fl = floorf(m->mu);
+    m->ii += fl >= 1.0f ? (uint64_t)(int)fl : 1u;     /* 1..3 for finite input */
+    m->mu = m->mu - fl;
+    return o;
+}
 
 /* a5 + a6 of one lane; appends (bit, pos) of ALL its chips to bits/pos/key (capacity ensured by the
  * caller: (core + warmup) chips at most).  soft_z / soft_chips: optional taps. */
 static uint64_t mm_lane(const float* d, uint64_t n, uint64_t core_start, uint64_t core_len,
                         uint64_t warmup, double lp_init, uint8_t* bits, uint64_t* pos, uint64_t* key,
-                        float* soft_z, float* soft_chips, uint64_t soft_cap)
+                        float* soft_z, float* soft_chips, uint64_t soft_cap, mm_t* end_state)
 {
     const uint64_t s0 = core_start > warmup ? core_start - warmup : 0;
     const uint64_t core_end = core_start + core_len;
-    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
-    const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
-    const float omega_lim = omega_mid * 0.0002f;
-    double lp = lp_init;
-    float mu = 0.5f, omega = 2.0f, last = 0.0f;
-    float win[8], ring[16];
-    uint64_t ii = s0, z_next = s0, chips = 0;
-    float warm_gain = 1.0f;
-    { const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_WARMGAIN") : NULL; if (e) warm_gain = (float)atof(e); }
-    if (s0 && g_exp_start_shift) ii += (uint64_t)g_exp_start_shift;     /* ORACLE_ZB_EXPERIMENT_TWOSTART, see channel_lanes */
-    {   /* ANALYSIS SWITCH (tools/lane_residual_r4.py only): start the lane's loop this many quarter samples later */
-        const char* e = s0 ? getenv("ORACLE_ZB_EXPERIMENT_PHASE0") : NULL;
-        if (e) { const int q = atoi(e); ii += (uint64_t)(q / 4); mu = 0.5f + 0.25f * (float)(q % 4); if (mu >= 1.0f) { mu -= 1.0f; ii++; } }
-    }
-    while (ii < core_end && ii + 8 <= n) {
-        while (z_next < ii + 8 && z_next < n) {
-            const float x = d[z_next];
-            lp = alpha * (double)x + one_minus * lp;
-            const float z = x - (float)lp;
-            ring[z_next & 15] = z;
-            if (soft_z && z_next - s0 < soft_cap) soft_z[z_next - s0] = z;
-            z_next++;
-        }
-        for (int k = 0; k < 8; k++) win[k] = ring[(ii + k) & 15];
-        const int imu = (int)rintf(mu * 128.0f);
-        float acc = 0.0f;
-        for (int k = 0; k < 8; k++) acc = fmaf(kMmseTaps[imu][k], win[7 - k], acc);
-        const float o = acc;
+    mm_t m;
+    mm_start(&m, s0, lp_init, s0);
+    uint64_t chips = 0;
+    while (m.ii < core_end && m.ii + 8 <= n) {
+        const uint64_t at = m.ii;
+        int imu;
+        const float o = mm_step(&m, d, n, &imu, soft_z, s0, soft_cap);
         if (soft_chips && chips < soft_cap) soft_chips[chips] = o;
-        if (bits) { bits[chips] = o > 0.0f; pos[chips] = ii; key[chips] = ii * 128u + (uint64_t)imu; }
+        if (bits) { bits[chips] = o > 0.0f; pos[chips] = at; key[chips] = at * 128u + (uint64_t)imu; }
         chips++;
-        const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
-        last = o;
-        omega = omega + gain_omega * mm;
-        {
-            const float x = omega - omega_mid;
-            const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
-            omega = omega_mid + c;
-        }
-        mu = mu + omega + (ii < core_start ? gain_mu * warm_gain : gain_mu) * mm;
-        const float fl = floorf(mu);
-        ii += fl >= 1.0f ? (uint64_t)(int)fl : 1u;     /* 1..3 for finite input */
-        mu = mu - fl;
     }
+    if (end_state) *end_state = m;
     return chips;
 }
 
@@ -399,6 +444,37 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
 /* Developer aid (tools/ only): when set, channel_lanes copies its stitched chip stream, the chips' window starts and the
  * lanes' first owned chips here. */
 uint8_t* g_dbg_bits = NULL; uint64_t* g_dbg_pos = NULL; uint64_t* g_dbg_first = NULL; uint64_t g_dbg_cap = 0, g_dbg_n = 0, g_dbg_lanes = 0;
+/* Developer aid: counters of the last channel_lanes calls (requests, repaired, given up again); not thread-safe sums are fine for a tool */
+uint64_t g_dbg_repair[4] = {0, 0, 0, 0};
+
+/* Frame repair: lane l's loop (state `m` at its core end) and its sink (state `s` at the seam, stream chip q0) go on with
+ * the frame the sink is busy with -- over the next lane's samples; where the lane after that takes over (hand_pos = window
+ * start of ITS first owned chip, stream chip hand_q; hand_q = 0: there is none) the sink returns to the stitched stream.
+ * Returns 1 if the frame completes (s holds it, *end_chip = the stream chip it ends at), 0 if it is given up. */
+static int repair_frame(const float* d, uint64_t n, mm_t m, uint64_t q0, uint32_t th, lane_t* s,
+                        uint64_t hand_pos, uint64_t hand_q, const uint8_t* sb, uint64_t total, uint64_t* end_chip)
+{
+    uint64_t c = 0;
+    int handed = 0;
+    while (m.ii + 8 <= n) {
+        /* the chip this step would produce lies at key 128 ii + rint(128 mu); from half a chip before the next-but-one
+         * lane's first owned chip (taken at the middle of its window-start sample) the chips are that lane's */
+        if (hand_q && m.ii * 128u + (uint64_t)(int)rintf(m.mu * 128.0f) + 128u >= hand_pos * 128u + 64u) { handed = 1; break; }
+        int imu;
+        const float o = mm_step(&m, d, n, &imu, NULL, 0, 0);
+        const int done = sink_chip(s, o, q0 + c, th);
+        c++;
+        if (done) { *end_chip = q0 + c - 1u; return 1; }
+        if (s->state == 0) return 0;        /* given up (a symbol without a chip word within the threshold, or a length > 127) */
+    }
+    if (!handed) return 0;                  /* the capture ends inside the frame */
+    for (uint64_t q = hand_q; q < total; q++) {
+        const int done = sink_chip(s, sb[q] ? 1.0f : -1.0f, q, th);
+        if (done) { *end_chip = q; return 1; }
+        if (s->state == 0) return 0;
+    }
+    return 0;
+}
 
 /* One channel: lanes -> stitched chip stream -> lane-local sinks. */
 static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint32_t channel,
@@ -414,121 +490,13 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
     uint8_t* sb = (uint8_t*)malloc(n + 16 + 4096);      /* stitched stream: at most one chip per sample */
     uint64_t* spos = (uint64_t*)malloc((n + 16 + 4096) * 8);
     uint64_t* o = (uint64_t*)malloc((n_lanes + 1) * 8); /* stream offset of every lane's first owned chip */
+    mm_t* ends = (mm_t*)malloc((n_lanes + 1) * sizeof(mm_t)); /* every lane's loop at its core end */
     uint64_t* seam = (uint64_t*)malloc((n_lanes + 1) * 8); /* per lane: XOR of its 48 chips before the seam with lane l-1's last 48 (bit 0 = the last chip) */
     uint64_t total = 0;
     uint64_t E = 0, prev_nc = 0, prev_hist = 0;
-    /* ANALYSIS SWITCH (tools/lane_residual.py only): verified hand-over.  Every lane runs P samples past its core end;
-     * the next lane takes over at the first chip from which R consecutive chips of both loops agree in value and in
-     * time (keys within half a sample), or at the end of the post-roll if they never do. */
-    const char* pr_env = getenv("ORACLE_ZB_EXPERIMENT_POSTROLL");
-    if (pr_env != NULL && atoi(pr_env) > 0) {
-        const uint64_t P = (uint64_t)atoi(pr_env);
-        const uint64_t R = getenv("ORACLE_ZB_EXPERIMENT_RUN") ? (uint64_t)atoi(getenv("ORACLE_ZB_EXPERIMENT_RUN")) : 48u;
-        const uint64_t cap2 = lane_cap + P;
-        uint8_t* pb = (uint8_t*)malloc(cap2); uint64_t* ppos = (uint64_t*)malloc(cap2 * 8); uint64_t* pkey = (uint64_t*)malloc(cap2 * 8);
-        uint8_t* cb = (uint8_t*)malloc(cap2); uint64_t* cpos = (uint64_t*)malloc(cap2 * 8); uint64_t* ckey = (uint64_t*)malloc(cap2 * 8);
-        uint64_t pnc = 0, pfrom = 0;
-        for (uint64_t l = 0; l < n_lanes; l++) {
-            const uint64_t cs = l * core;
-            const uint64_t nc = mm_lane(d, n, cs, core + P, warmup, lp_in[l], cb, cpos, ckey, NULL, NULL, 0);
-            uint64_t cfrom = 0;
-            seam[l] = 0;
-            if (l > 0) {
-                uint64_t c0 = 0;
-                while (c0 < nc && cpos[c0] + 3 < cs) c0++;
-                uint64_t i = pfrom, run = 0, last_i = 0, pto = pnc;
-                int found = 0;
-                for (uint64_t j = c0; j < nc; j++) {
-                    while (i < pnc && pkey[i] + 64 < ckey[j]) i++;
-                    if (i >= pnc) break;
-                    const int ok = pkey[i] <= ckey[j] + 64 && pb[i] == cb[j];
-                    if (ok && run > 0 && i == last_i + 1) run++; else run = ok ? 1 : 0;
-                    last_i = i;
-                    if (run >= R) { found = 1; pto = i + 1; cfrom = j + 1; break; }
-                }
-                if (!found) {
-                    seam[l] = 0xFFFFFFFFFFFFull;
-                    const uint64_t Ee = pnc ? pkey[pnc - 1] + 128u : cs * 128u;
-                    cfrom = c0;
-                    while (cfrom < nc && ckey[cfrom] < Ee) cfrom++;
-                }
-                o[l - 1] = total;
-                for (uint64_t j = pfrom; j < pto; j++) { sb[total] = pb[j]; spos[total] = ppos[j]; total++; }
-            }
-            { uint8_t* t8 = pb; pb = cb; cb = t8; uint64_t* t = ppos; ppos = cpos; cpos = t; t = pkey; pkey = ckey; ckey = t; }
-            pnc = nc; pfrom = cfrom;
-        }
-        if (n_lanes) { o[n_lanes - 1] = total; for (uint64_t j = pfrom; j < pnc; j++) { sb[total] = pb[j]; spos[total] = ppos[j]; total++; } }
-        free(pb); free(ppos); free(pkey); free(cb); free(cpos); free(ckey);
-    } else {
-    /* ANALYSIS SWITCH (tools/lane_gaps_r4.py only; never set in tests or by the product's parity runs): lane boundaries in the
-     * gaps between frames.  b[l] = the sample nearest l core (within half a core) at which the discriminator output has looked
-     * like noise for G samples (mean |d| over them above 1.2: a frame's MSK gives 0.8, noise pi/2, a neighbour's leakage more);
-     * no such sample: l core.  A lane starts its loop `warmup` samples before b[l] with the sequential filter's own state. */
-    uint64_t* bnd = NULL;
-    double* lp_seq = NULL;
-    const char* gap_env = getenv("ORACLE_ZB_EXPERIMENT_GAPS");
-    if (gap_env != NULL && atoi(gap_env) > 0 && n_lanes > 1) {
-        const uint64_t G = (uint64_t)atoi(gap_env);
-        bnd = (uint64_t*)malloc((n_lanes + 1) * 8);
-        lp_seq = (double*)malloc(n_lanes * 8);
-        uint8_t* gap = (uint8_t*)calloc(n + 1, 1);              /* gap[t]: d[t-G+1 .. t] is noise */
-        double acc = 0.0;
-        for (uint64_t t = 0; t < n; t++) {
-            acc += fabs((double)d[t]);
-            if (t >= G) acc -= fabs((double)d[t - G]);
-            gap[t] = t + 1 >= G && acc > 1.2 * (double)G;
-        }
-        bnd[0] = 0; bnd[n_lanes] = n;
-        uint64_t moved = 0;
-        for (uint64_t l = 1; l < n_lanes; l++) {
-            const uint64_t c = l * core;
-            uint64_t best = c;
-            for (uint64_t k = 0; k < core / 2; k++) {
-                if (c + k < n && gap[c + k]) { best = c + k; break; }
-                if (c >= k + 1 && c - k > bnd[l - 1] + 64 && gap[c - k]) { best = c - k; break; }
-            }
-            if (best <= bnd[l - 1] + 64) best = c > bnd[l - 1] + 64 ? c : bnd[l - 1] + 64;
-            if (best > n) best = n;
-            moved += best != c;
-            bnd[l] = best;
-        }
-        free(gap);
-        const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
-        double lp = 0.0;
-        uint64_t l = 1;
-        lp_seq[0] = 0.0;
-        for (uint64_t t = 0; t < n && l < n_lanes; t++) {
-            while (l < n_lanes && (bnd[l] > warmup ? bnd[l] - warmup : 0) == t) lp_seq[l++] = lp;
-            lp = alpha * (double)d[t] + one_minus * lp;
-        }
-        while (l < n_lanes) lp_seq[l++] = lp;
-        if (getenv("ORACLE_ZB_EXPERIMENT_GAPS_VERBOSE")) fprintf(stderr, "gaps: %llu of %llu boundaries moved\n", (unsigned long long)moved, (unsigned long long)(n_lanes - 1));
-        free(lb); free(lpos); free(lkey);
-        const uint64_t cap2 = 2 * (uint64_t)core + warmup + 80;
-        lb = (uint8_t*)malloc(cap2); lpos = (uint64_t*)malloc(cap2 * 8); lkey = (uint64_t*)malloc(cap2 * 8);
-    }
     for (uint64_t l = 0; l < n_lanes; l++) {
-        const uint64_t cs = bnd ? bnd[l] : l * core, ce = bnd ? bnd[l + 1] : cs + core;
-        if (bnd && ce <= cs) { o[l] = total; seam[l] = 0; continue; }
-        /* ANALYSIS SWITCH: the timing loop of a lane that starts inside a frame can hang at the half-chip point for hundreds of
-         * chips (Mueller & Mueller's hang-up).  Run the warm-up from two starts one sample (half a chip) apart and keep the one
-         * with the wider eye: sum |interpolated sample| over the last E chips before the core. */
-        if (l > 0 && getenv("ORACLE_ZB_EXPERIMENT_TWOSTART") != NULL) {
-            const uint64_t Ew = (uint64_t)atoi(getenv("ORACLE_ZB_EXPERIMENT_TWOSTART"));
-            float* sc = (float*)malloc((warmup + 64) * sizeof(float));
-            double eye[2] = {0.0, 0.0};
-            for (int c = 0; c < 2; c++) {
-                g_exp_start_shift = c;
-                const uint64_t s0w = cs > warmup ? cs - warmup : 0;
-                const uint64_t k = mm_lane(d, n, s0w, cs - s0w, 0, bnd ? lp_seq[l] : lp_in[l], NULL, NULL, NULL, NULL, sc, warmup + 64);
-                for (uint64_t j = k > Ew ? k - Ew : 0; j < k; j++) eye[c] += fabs((double)sc[j]);
-            }
-            free(sc);
-            g_exp_start_shift = eye[1] > eye[0] ? 1 : 0;
-        }
-        const uint64_t nc = mm_lane(d, n, cs, ce - cs, warmup, bnd ? lp_seq[l] : lp_in[l], lb, lpos, lkey, NULL, NULL, 0);
-        g_exp_start_shift = 0;
+        const uint64_t cs = l * core, ce = cs + core;
+        const uint64_t nc = mm_lane(d, n, cs, ce - cs, warmup, lp_in[l], lb, lpos, lkey, NULL, NULL, 0, &ends[l]);
         uint64_t f = 0;
         seam[l] = l ? 0xFFFFFFFFFFFFull : 0;                        /* no comparison made: nothing verified */
         if (l > 0) {
@@ -561,8 +529,6 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         prev_hist = 0;                                              /* last 64 chips of the lane, MSB first */
         for (uint64_t j = (nc >= 64 ? nc - 64 : 0); j < nc; j++) prev_hist = (prev_hist << 1) | lb[j];
     }
-    free(bnd); free(lp_seq);
-    }
     o[n_lanes] = total;
     if (g_dbg_bits) {
         g_dbg_n = total < g_dbg_cap ? total : g_dbg_cap;
@@ -577,57 +543,82 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         memset(&s, 0, sizeof(s));
         enter_search(&s);
         uint64_t q_start = o[l] > ORACLE_ZB_SINK_WARM ? o[l] - ORACLE_ZB_SINK_WARM : 0;
-        /* ANALYSIS SWITCH (tools/lane_residual.py; never set in tests or by the product's parity runs): the sequential
-         * sink is busy with the frame kept last until its last chip and searches again, register cleared, from the
-         * next one; a lane's sink that starts inside that frame can false-sync on payload symbols, and a phantom's
-         * bogus length can run over the next real frame.  With the switch the lane's sink starts behind the kept
-         * frame instead: what that rule would recover of the lanes' residual. */
-        if (getenv("ORACLE_ZB_EXPERIMENT_RESTART") != NULL && have_kept && q_start <= busy_end) q_start = busy_end + 1;
+        lane_t snap;
+        int have_snap = 0;
         for (uint64_t q = q_start; q < total; q++) {
             if (s.state == 0 && s.preamble_cnt == 0 && q >= o[l + 1]) break;   /* idle past the lane */
+            if (q == o[l + 1] && s.state != 0) { snap = s; have_snap = 1; }     /* busy with a synchronised frame at the seam */
+            const int before = s.state;
             const int done = sink_chip(&s, sb[q] ? 1.0f : -1.0f, q, threshold);  /* trigger = chip index */
+            const int gave_up = !done && before != 0 && s.state == 0 && s.chip_err;
+            if (!done && !gave_up) continue;
             /* a frame belongs to the lane that owns the chip completing its SFD: sinks may first
              * match different preamble symbols, but they all find the SFD at the same chip */
-            if (done && (s.sync < o[l] || s.sync >= o[l + 1])) { enter_search(&s); continue; }
-            if (done) {
-                /* resolve: the sequential sink is busy until the end of the frame it kept last */
-                if (have_kept && s.trigger <= busy_end) { enter_search(&s); continue; }
-                have_kept = 1;
-                busy_end = q;
-                if (*n_out < cap) {
-                    snout_pkt* p = &out[*n_out];
-                    memset(p, 0, sizeof(*p));
-                    p->sample_index = first_index + spos[s.sync >= 319u ? s.sync - 319u : 0u];
-                    p->proto = 1;
-                    p->channel = (uint16_t)channel;
-                    p->len = (uint16_t)s.packetlen_cnt;
-                    unsigned scaled = (s.lqi / 8) << 3;
-                    p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
-                    p->aux = (uint32_t)l;
-                    /* SNOUT_PKT_ZB_SEAM_DISAGREED.  Seams inside the frame = hand-overs from one lane's timing loop to
-                     * the next between the trigger chip and the last chip.  The two loops ran side by side over the 48
-                     * chips before the seam (seam[m]: XOR of their decisions, bit 0 = the last chip before it); if they
-                     * decided any of those that belong to the frame differently, the frame's chips depend on which
-                     * loop is asked -- the one sequential loop's may differ too. */
-                    for (uint64_t m = 1; m < n_lanes; m++) {
-                        if (o[m] <= s.trigger || o[m] > q) continue;
-                        const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
-                        const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
-                        if (seam[m] & mask) p->flags |= 4u;
-                    }
-                    memcpy(p->bytes, s.pkt, (size_t)s.packetlen_cnt);
-                    if (s.packetlen_cnt >= 3) {
-                        uint16_t c = oracle_crc16_154(s.pkt, s.packetlen_cnt - 2);
-                        p->crc_ok = (uint8_t)(((c & 0xFF) == s.pkt[s.packetlen_cnt - 2]) &&
-                                              ((c >> 8) == s.pkt[s.packetlen_cnt - 1]));
-                    }
-                }
-                (*n_out)++;
-                enter_search(&s);
+            if (s.sync < o[l] || s.sync >= o[l + 1]) { if (done) enter_search(&s); continue; }
+            lane_t rs;
+            const lane_t* fin = &s;
+            const uint64_t idx = spos[s.sync >= 319u ? s.sync - 319u : 0u];
+            uint64_t end_chip = q;
+            int crc_ok = 0;
+            if (done && s.packetlen_cnt >= 3) {
+                const uint16_t c = oracle_crc16_154(s.pkt, s.packetlen_cnt - 2);
+                crc_ok = ((c & 0xFF) == s.pkt[s.packetlen_cnt - 2]) && ((c >> 8) == s.pkt[s.packetlen_cnt - 1]);
             }
+            if (g_zb_repair && have_snap && q >= o[l + 1] && (gave_up || !crc_ok || g_zb_repair == 2)) {
+                g_dbg_repair[0]++;
+                rs = snap;
+                uint64_t rend = 0;
+                /* lane l + 2 takes over again if it owns chips (hand_q > 0 then: it is not the channel's first lane) */
+                const int hb = l + 2 < n_lanes && o[l + 2] < o[l + 3] && core <= (1u << 23);     /* (lane-relative keys in 32 bits) */
+                const int ok = repair_frame(d, n, ends[l], o[l + 1], threshold, &rs, hb ? spos[o[l + 2]] : 0u, hb ? o[l + 2] : 0u,
+                                            sb, total, &rend);
+                g_dbg_repair[ok ? 1 : 2]++;
+                if (!ok) { if (done) enter_search(&s); continue; }
+                fin = &rs;
+                end_chip = rend;
+                crc_ok = 0;
+                if (rs.packetlen_cnt >= 3) {
+                    const uint16_t c = oracle_crc16_154(rs.pkt, rs.packetlen_cnt - 2);
+                    crc_ok = ((c & 0xFF) == rs.pkt[rs.packetlen_cnt - 2]) && ((c >> 8) == rs.pkt[rs.packetlen_cnt - 1]);
+                }
+            } else if (gave_up) {
+                continue;
+            }
+            /* resolve: the sequential sink is busy until the end of the frame it kept last */
+            if (have_kept && s.trigger <= busy_end) { if (done) enter_search(&s); continue; }
+            have_kept = 1;
+            busy_end = end_chip;
+            if (*n_out < cap) {
+                snout_pkt* p = &out[*n_out];
+                memset(p, 0, sizeof(*p));
+                p->sample_index = first_index + idx;
+                p->proto = 1;
+                p->channel = (uint16_t)channel;
+                p->len = (uint16_t)fin->packetlen_cnt;
+                unsigned scaled = (fin->lqi / 8) << 3;
+                p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
+                p->aux = (uint32_t)l;
+                /* SNOUT_PKT_ZB_SEAM_DISAGREED.  Seams inside the frame = hand-overs from one lane's timing loop to
+                 * the next between the trigger chip and the last chip.  The two loops ran side by side over the 48
+                 * chips before the seam (seam[m]: XOR of their decisions, bit 0 = the last chip before it); if they
+                 * decided any of those that belong to the frame differently, the frame's chips depend on which
+                 * loop is asked -- the one sequential loop's may differ too.  A repaired frame (SNOUT_PKT_ZB_REPAIRED)
+                 * has no seams. */
+                if (fin == &rs) p->flags |= 8u;
+                else for (uint64_t m = 1; m < n_lanes; m++) {
+                    if (o[m] <= s.trigger || o[m] > q) continue;
+                    const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
+                    const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
+                    if (seam[m] & mask) p->flags |= 4u;
+                }
+                memcpy(p->bytes, fin->pkt, (size_t)fin->packetlen_cnt);
+                p->crc_ok = (uint8_t)crc_ok;
+            }
+            (*n_out)++;
+            if (done) enter_search(&s);
         }
     }
-    free(seam); free(o); free(spos); free(sb); free(lkey); free(lpos); free(lb); free(lp_in);
+    free(ends); free(seam); free(o); free(spos); free(sb); free(lkey); free(lpos); free(lb); free(lp_in);
 }
 
 int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,
@@ -657,7 +648,7 @@ int oracle_zigbee_lane_soft(const float* iq, uint64_t n, uint32_t core, uint32_t
     const uint64_t n_lanes = (n + core - 1) / core;
     double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
     *n_chips = mm_lane(d, n, (uint64_t)lane * core, core, warmup, lane < n_lanes ? lp_in[lane] : 0.0,
-                       NULL, NULL, NULL, z, chips, cap);
+                       NULL, NULL, NULL, z, chips, cap, NULL);
     free(lp_in);
     free(d);
     return 0;

@@ -217,6 +217,9 @@ struct ZbCtx {
     // first_owned|owned|offs|tsum|slot_total, chip streams
     DevBuf d_d, d_TR, d_lane_out, d_cand, d_lane_u32, d_stream;
     DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
+    DevBuf d_lane_end, d_snap, d_req;         // frame repair: every lane's loop at its core end, sinks busy at a seam, requests
+    bool repair = true;                       // SNOUT_ZB_REPAIR=0: the lanes alone (rounds 1-4; A/B and tests only)
+    uint32_t tail_prio = 3;                   // SNOUT_ZB_TAIL_PRIO: bit 0 zb_walk, bit 1 zb_repair run at s_setprio 3 (A/B)
     double d64 = 0, dcore = 0, dfirst = 0;
     uint64_t nsb = 0;
 
@@ -224,7 +227,7 @@ struct ZbCtx {
              uint32_t warmup, uint32_t batch_cap = 1);
     void destroy();
     int reserve(uint64_t n_channel_samples, uint32_t segs = 1);
-    int launch_sinks(const SegBatch& segs, hipStream_t st);
+    int launch_sinks(uint64_t n, const SegBatch& segs, hipStream_t st);
     // front end (discriminator, carry-in, lanes) and tail (stitch, sinks, ordered compaction into
     // s.d_out / s.d_totals); no host sync
     // d_iq == nullptr: the fused channelizer has already written d and S (see pfb_target)

@@ -96,10 +96,13 @@ struct snout_rx {
     bool wide = false;
     // Work sets: the tail of segment i overlaps the front end of i+1.  BTLE has three, so that with
     // three segments in flight the set a new segment takes was released by a segment already
-    // collected (no wait to enqueue); the much larger Zigbee sets come in two.
+    // collected (no wait to enqueue).  Zigbee has three as well since round 5: its tail holds two latency-bound
+    // kernels (zb_walk, zb_repair: a few waves that run for one to two milliseconds), and with a third set the front
+    // end of segment i + 2 does not wait for them.  Every work set has its own tail stream, so the tails of
+    // consecutive segments overlap each other too.
     BtleCtx btle, btle2, btle3;
-    ZbCtx zb2;                // (second Zigbee work set; the first is `zb`)
-    hipStream_t tail_stream = nullptr;
+    ZbCtx zb2, zb3;           // (second and third Zigbee work set; the first is `zb`)
+    hipStream_t tail_streams[3] = {nullptr, nullptr, nullptr};
     bool sync_call = false;   // inside snout_rx_process*: nothing to overlap, the tail stays on the caller's stream
     ZbCtx zb;
     PfbCtx pfb;
@@ -130,7 +133,7 @@ static BtleCtx& btle_of(snout_rx* h, const ResultSlot& s)
 {
     return s.work_set == 0 ? h->btle : (s.work_set == 1 ? h->btle2 : h->btle3);
 }
-static ZbCtx& zb_of(snout_rx* h, const ResultSlot& s) { return s.work_set ? h->zb2 : h->zb; }
+static ZbCtx& zb_of(snout_rx* h, const ResultSlot& s) { return s.work_set == 0 ? h->zb : (s.work_set == 1 ? h->zb2 : h->zb3); }
 
 // Enqueue every kernel of one segment, results into slot s.  No host synchronisation.
 // BTLE: the front end (demod+correlate, or channelizer+correlate) runs on the caller's stream `st`;
@@ -152,7 +155,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // -> 9.9 ms); behind a 1e9-sample front end the separate stream is worth 5 %.
     const uint64_t ch_samples = (h->wide ? h->pfb.n_out_for(s.n_in) * h->cfg.n_channels : s.n_in) * s.segs.count;
     const bool inline_tail = h->sync_call || (h->cfg.proto == SNOUT_PROTO_BTLE && ch_samples < (1ull << 26));
-    hipStream_t tail = inline_tail ? st : h->tail_stream;
+    hipStream_t tail = inline_tail ? st : h->tail_streams[s.work_set];
     // (the first kernel's start event ev_k0 also marks the start of the segment: every event on the
     //  caller's stream is a barrier packet, so there is no separate one)
     // the tail that last used this work set must be done; usually it is, and a wait that is not
@@ -349,6 +352,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         uint16_t ch = (uint16_t)c.channel;
         rc = h->zb.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (!rc) rc = h->zb2.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
+        if (!rc) rc = h->zb3.init(1, &ch, c.chip_threshold, c.zb_core, c.zb_warmup);
         if (rc) goto fail;
     } else if ((c.proto == SNOUT_PROTO_BTLE && c.n_channels == 40) ||
                (c.proto == SNOUT_PROTO_ZIGBEE && c.n_channels == 16)) {
@@ -367,13 +371,14 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle2.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments);
         if (!rc && c.proto == SNOUT_PROTO_BTLE) rc = h->btle3.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments);
         if (!rc && c.proto == SNOUT_PROTO_ZIGBEE) rc = h->zb2.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
+        if (!rc && c.proto == SNOUT_PROTO_ZIGBEE) rc = h->zb3.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
         if (rc) goto fail;
     } else {
         set_last_error("configuration proto=%u n_channels=%u not supported (BTLE: 1 or 40, "
                        "Zigbee: 1 or 16)", c.proto, c.n_channels);
         goto fail;
     }
-    h->zb.auto_shape = h->zb2.auto_shape = zb_auto;
+    h->zb.auto_shape = h->zb2.auto_shape = h->zb3.auto_shape = zb_auto;
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
     for (int k = 0; k < 3; k++) {
         if (hipEventCreate(&h->ws_free[k]) != hipSuccess) { rc = SNOUT_EHIP; goto fail; }
@@ -384,10 +389,12 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
             goto fail;
         }
     }
-    if (hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess) {
-        set_last_error("hipStreamCreate failed");
-        rc = SNOUT_EHIP;
-        goto fail;
+    for (int k = 0; k < 3; k++) {
+        if (hipStreamCreateWithFlags(&h->tail_streams[k], hipStreamNonBlocking) != hipSuccess) {
+            set_last_error("hipStreamCreate failed");
+            rc = SNOUT_EHIP;
+            goto fail;
+        }
     }
     {   // highest priority: the short record copy must not queue behind the next segment's blocks
         int least = 0, greatest = 0;
@@ -413,9 +420,10 @@ void snout_rx_destroy(snout_rx* h)
     h->btle.destroy();
     h->btle2.destroy();
     h->btle3.destroy();
-    if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
+    for (int k = 0; k < 3; k++) if (h->tail_streams[k]) (void)hipStreamDestroy(h->tail_streams[k]);
     h->zb.destroy();
     h->zb2.destroy();
+    h->zb3.destroy();
     h->pfb.destroy();
     h->d_iq.release();
     for (auto& s : h->slots) s.destroy();
@@ -470,7 +478,7 @@ int snout_rx_submit_batch_dev(snout_rx* h, const void* const* iq_devs, uint32_t 
     }
     SNOUT_HIP(hipSetDevice(h->device));
     ResultSlot& s = h->slots[(h->head + h->pending) % snout_rx::kSlots];
-    s.work_set = (int)(h->n_submitted++ % (h->cfg.proto == SNOUT_PROTO_BTLE ? 3u : 2u));
+    s.work_set = (int)(h->n_submitted++ % 3u);
     s.iq = iq_dev;
     s.n_in = n_samples;
     s.first_index = first0;

@@ -184,6 +184,13 @@ struct ZbLaneOut {
     uint64_t hist_cand;     // the 64 chips ending at the last candidate
 };
 
+// Where a lane's loop stands at its core end: what the frame repair (zb_repair) goes on from.
+struct ZbLaneEnd {
+    double lp;              // filter state before lane-relative sample rce = (core start - lane start) + core
+    float mu, omega, last;  // the loop after its last step
+    uint32_t ii;            // lane-relative window start of the chip it would produce next (>= rce unless the segment ended)
+};
+
 // One wave = 64 lanes, thread = lane.  Per 64-sample tile: the thread's own 64 discriminator
 // samples arrive in registers (prefetched during the previous tile), the fp64 IIR turns them into
 // z (LDS row of the lane: 8 samples of history + the tile), then the M&M steps whose window starts
@@ -195,7 +202,8 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     const float* __restrict__ d, uint64_t d_stride, uint64_t n, uint32_t nt, uint32_t lanes_per_slot,
     uint32_t total_lanes, uint32_t core, uint32_t warmup, const float* __restrict__ mmse,
     const double* __restrict__ lp_in,
-    uint32_t* __restrict__ TR, ZbLaneOut* __restrict__ lane_out, uint32_t* __restrict__ cand_keys,
+    uint32_t* __restrict__ TR, ZbLaneOut* __restrict__ lane_out, ZbLaneEnd* __restrict__ lane_end,
+    uint32_t* __restrict__ cand_keys,
     float* __restrict__ soft_z, float* __restrict__ soft_chips, uint32_t soft_lane, uint32_t soft_cap,
     uint32_t* __restrict__ soft_n)
 {
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
     const float omega_lim = omega_mid * 0.0002f;
     double lp = active ? lp_in[g] : 0.0;
+    double lp_rce = lp;
     float mu = 0.5f, omega = 2.0f, last = 0.0f;
     uint32_t ii = 0, n_chips = 0, t_last = 0, c0 = 0, cand_n = 0;
     uint64_t hist = 0, hist_cand = 0;
@@ -251,6 +260,7 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
 
     for (uint32_t tile = 0; tile < nt; tile++) {
         const uint32_t r0 = tile * 64u;
+        if (r0 == rce) lp_rce = lp;     // the filter at the core end (the last tile; lane 0 of a channel: earlier)
         // The tile is consumed in two halves of 32 samples (the LDS row holds 8 + 32 samples, which
         // lets ten waves share a CU): a5, DC removal (sequential fp64 recurrence), then a6, the M&M
         // steps whose window ends inside the half.  The last tile only feeds the windows that start
@@ -365,6 +375,9 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
         lo.nc = n_chips; lo.t_last = t_last; lo.c0 = cand_n ? c0 : n_chips; lo.cand_n = cand_n;
         lo.hist_end = hist; lo.hist_cand = hist_cand;
         lane_out[g] = lo;
+        ZbLaneEnd le;
+        le.lp = lp_rce; le.mu = mu; le.omega = omega; le.last = last; le.ii = ii;
+        lane_end[g] = le;
     }
     if constexpr (TAP) { if (tap && soft_n) *soft_n = n_chips; }
 }
@@ -388,10 +401,11 @@ __global__ __launch_bounds__(256) void zb_stitch(const ZbLaneOut* __restrict__ l
                                                  uint32_t lanes_per_slot, uint32_t core, uint32_t warmup,
                                                  uint32_t tiles_per_slot, uint32_t* __restrict__ first_owned,
                                                  uint32_t* __restrict__ owned, uint32_t* __restrict__ tsum,
-                                                 unsigned long long* __restrict__ seam)
+                                                 unsigned long long* __restrict__ seam, uint32_t* __restrict__ req)
 {
     __shared__ uint32_t lds4[4];
     const uint32_t slot = blockIdx.y, tile = blockIdx.x;
+    if (slot == 0u && tile == 0u && threadIdx.x == 0u) req[0] = 0u;     // zb_walk's repair requests of this segment
     uint32_t s = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4u; k++) {
@@ -573,11 +587,22 @@ struct SinkState {
     uint32_t trigger;   // stream index of the chip that completed the first preamble match
     uint32_t c0, c1, c2;   // running FCS: after all bytes, one byte ago, two bytes ago
     uint32_t b_prev, b_last;   // the last two PSDU bytes
+    uint32_t chip_err;  // the last return to search came from a symbol without a chip word within the threshold
+};
+
+// A sink that is busy with a synchronised frame where its lane's chips end (zb_walk) -- at the last symbol
+// boundary before that seam -- for zb_repair to go on from with the lane's own loop (oracle_zigbee.c "Frame repair").
+struct ZbSnap {
+    SinkState s;
+    uint32_t q_b;       // stream index of the first chip of the symbol the sink is in (q_b <= own1 < q_b + 32)
+    uint32_t own1;      // the next lane's first owned chip
+    uint32_t slot;      // record slot of the lane that the frame occupies
+    uint32_t pad;
 };
 
 __device__ __forceinline__ void enter_search(SinkState& s)
 {
-    s.state = 0; s.shift = 0; s.preamble_cnt = 0; s.chip_cnt = 0; s.packet_byte = 0;
+    s.state = 0; s.shift = 0; s.preamble_cnt = 0; s.chip_cnt = 0; s.packet_byte = 0; s.chip_err = 0;
 }
 
 __device__ __forceinline__ uint32_t chip_dist(uint32_t shift, uint32_t word)
@@ -661,7 +686,7 @@ __device__ __forceinline__ bool sink_symbol(SinkState& s, uint32_t th, uint8_t* 
         return false;
     }
     const int c = decode_chips(s, th);
-    if (c == 0xFF) { enter_search(s); return false; }
+    if (c == 0xFF) { enter_search(s); s.chip_err = 1u; return false; }
     if (s.byte_index == 0) s.packet_byte = c; else s.packet_byte |= c << 4;
     s.byte_index++;
     if ((s.byte_index & 1) != 0) return false;
@@ -719,6 +744,32 @@ __global__ __launch_bounds__(256) void zb_match(const unsigned long long* __rest
     pairs[(uint64_t)slot * stream_words + wi] = make_ulonglong2(cur, ((uint64_t)m_hi << 32) | m_lo);
 }
 
+// Lane-relative window start of chip j of lane gt, from its tile records: the last tile with cstart <= j, its first
+// window start, plus the window advances of the chips before j in it (2-bit codes step - 1, half A then half B, latest
+// chip low).
+__device__ __forceinline__ uint32_t lane_chip_pos(const uint32_t* __restrict__ TR, uint32_t nt, uint32_t gt, uint32_t j)
+{
+    const uint32_t w = gt >> 6, row = gt & 63u;
+    uint32_t lo = 0, hi2 = nt;          // last tile with cstart <= j and nc > 0 reaching j
+    while (hi2 - lo > 1u) {
+        const uint32_t mid = (lo + hi2) >> 1;
+        if (TR[tr_index(w, nt, mid, 7, row)] <= j) lo = mid; else hi2 = mid;
+    }
+    const uint32_t i = j - TR[tr_index(w, nt, lo, 7, row)];
+    const uint32_t ncw = TR[tr_index(w, nt, lo, 6, row)];
+    const uint32_t n_a = ncw >> 16, n_b = (ncw & 0xFFFFu) - n_a;
+    const uint64_t ca = (uint64_t)TR[tr_index(w, nt, lo, 2, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 3, row)] << 32);
+    const uint64_t cb = (uint64_t)TR[tr_index(w, nt, lo, 4, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 5, row)] << 32);
+    auto code_sum = [](uint64_t word, uint32_t n_in, uint32_t first) -> uint32_t {
+        // sum of the codes of the first `first` chips of a word holding n_in chips
+        if (first == 0u) return 0u;
+        const uint64_t x = word >> (2u * (n_in - first));
+        return (uint32_t)__popcll(x & 0x5555555555555555ull) + 2u * (uint32_t)__popcll(x & 0xAAAAAAAAAAAAAAAAull);
+    };
+    const uint32_t ia = i < n_a ? i : n_a, ib = i < n_a ? 0u : i - n_a;
+    return TR[tr_index(w, nt, lo, 8, row)] + i + code_sum(ca, n_a, ia) + code_sum(cb, n_b, ib);
+}
+
 // Sequential reader of one channel's {chips, match} pairs: the sink only moves forward, so the words around
 // the cursor stay in registers and the next two are always in flight.
 struct ChipReader {
@@ -761,16 +812,19 @@ struct ChipReader {
 #ifdef SNOUT_ZB_WALK_STAMPS
 __device__ unsigned long long g_walk_stamps[8192 * 4];      // diagnostic build (tools/walk_stamps.py): per wave iterations, cycles, lane-iterations searching / in a symbol
 #endif
-__global__ __launch_bounds__(256) void zb_walk(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void zb_walk(
     const ulonglong2* __restrict__ pairs,
     uint64_t stream_words, const uint32_t* __restrict__ offs,
     const uint32_t* __restrict__ first_owned, const uint32_t* __restrict__ slot_total,
     const uint32_t* __restrict__ TR, uint32_t nt, uint32_t lanes_per_slot, uint32_t total_lanes,
     uint32_t core, uint32_t warmup, uint32_t th, const uint16_t* __restrict__ slot_channel,
-    SegBatch segs, snout_pkt* __restrict__ stage, uint32_t K, uint32_t* __restrict__ lane_cnt)
+    SegBatch segs, snout_pkt* __restrict__ stage, uint32_t K, uint32_t* __restrict__ lane_cnt,
+    ZbSnap* __restrict__ snaps, uint32_t* __restrict__ req,        // req[0]: count, req[1 + i]: lane of repair request i
+    uint32_t hiprio)
 {
-    // a few latency-bound waves that run beside the next segment's front end: issue them first
-    __builtin_amdgcn_s_setprio(3);
+    // a few latency-bound waves that run beside the next segment's front end: issue them first -- when something waits
+    // for them (two work sets); with three the front end is the critical path and they take what it leaves
+    if (hiprio) __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const bool exists = g < total_lanes;            // lanes past the end still help their wave decode
@@ -786,6 +840,8 @@ __global__ __launch_bounds__(256) void zb_walk(
     s.byte_index = s.packetlen = s.packetlen_cnt = s.payload_cnt = 0;
     s.lqi = s.lqi_cnt = 0; s.trigger = 0; s.c0 = s.c1 = s.c2 = 0; s.b_prev = s.b_last = 0;
     uint32_t n_pk = 0, sync_q = 0;
+    bool snapped = false;           // this sink was busy with a synchronised frame at its lane's seam (snaps[g] holds it there)
+    const bool has_next = li + 1u < lanes_per_slot;
     uint32_t q = own0 > kSinkWarmChips ? own0 - kSinkWarmChips : 0u;
     ChipReader rd;
     rd.open(sw, q);
@@ -799,7 +855,7 @@ __global__ __launch_bounds__(256) void zb_walk(
         st_srch += __popcll(__ballot(alive && s.state == 0 && s.preamble_cnt == 0));
         st_sym += __popcll(__ballot(alive && !(s.state == 0 && s.preamble_cnt == 0)));
 #endif
-        bool fin = false, stepped = false;
+        bool fin = false, stepped = false, gave_up = false;
         // ---- payload, cooperatively.  A lane inside the payload of a frame (state 2, at a byte
         //      boundary, at least two bytes to go) would otherwise take one symbol per iteration while
         //      the other 63 lanes of the wave wait: instead the whole wave decodes up to 64 symbols of
@@ -834,6 +890,10 @@ __global__ __launch_bounds__(256) void zb_walk(
             uint32_t S = 2u * rem < W ? 2u * rem : W;
             const uint32_t fit = (tot0 - q0) >> 5;                 // symbols whose last chip is in the stream
             S = S < fit ? S : fit;
+            // a round stops at the source lane's seam: the sink crosses it symbol by symbol (one-symbol path), which is
+            // where the snapshot for the frame repair is taken
+            const uint32_t own1_0 = (uint32_t)__shfl((int)own1, from);
+            if (q0 < own1_0) { const uint32_t upto = (own1_0 - q0) >> 5; S = S < upto ? S : upto; }
             uint32_t nwv = 0xFF00u;                                 // distance 255: invalid
             if (has && sl < S) {
                 const uint32_t qe = q0 + 31u + 32u * sl;            // last chip of symbol `sl`
@@ -964,20 +1024,35 @@ __global__ __launch_bounds__(256) void zb_walk(
                     alive = false;                      // the stream ends inside the frame
                 } else {
                     rd.seek(qb);
+                    if (has_next && !snapped && s.state != 0 && q <= own1 && own1 <= qb) {
+                        // busy with a synchronised frame at the seam: the sink as it stands at this symbol boundary
+                        snapped = true;
+                        ZbSnap sn;
+                        sn.s = s; sn.q_b = q; sn.own1 = own1; sn.slot = n_pk; sn.pad = 0u;
+                        snaps[g] = sn;
+                    }
                     s.shift = rd.window32(qb);
                     uint8_t* pb = (uint8_t*)(uintptr_t)pb_me;
                     const int state_before = s.state;
                     fin = sink_symbol(s, th, pb);
                     if (state_before == 0 && s.state == 1) sync_q = qb;      // the chip that completed the SFD
+                    gave_up = !fin && state_before != 0 && s.state == 0 && s.chip_err != 0u;
                     q = qb + 1u;
                 }
             }
         }
         if (alive && q >= total) alive = false;
-        if (fin) {
+        if (fin || gave_up) {
             // Sinks may first match different preamble symbols but find the SFD at the same chip:
             // the frame belongs to the lane that owns that chip.
-            if (sync_q >= own0 && sync_q < own1) {
+            const uint32_t len = fin ? (uint32_t)s.packetlen_cnt : 0u;
+            // FCS: CRC-16 over all but the last two bytes == those two bytes (LE)
+            const bool fcs_ok = fin && len >= 3u && s.c2 == (s.b_prev | (s.b_last << 8));
+            // Frame repair (oracle_zigbee.c): a frame this sink was busy with at its lane's seam and then gave up at a
+            // symbol, or finished with a bad FCS, is received again by the lane's own loop going on (zb_repair); until
+            // then its record slot is void (trigger 0xFFFFFFFF: zb_resolve passes over it)
+            const bool ask = snapped && !fcs_ok;
+            if (sync_q >= own0 && sync_q < own1 && (fin || ask)) {
                 if (n_pk < K) {
                     // window start of the trigger chip: chip j of the lane gt that owns it (this lane
                     // or one before it), found in that lane's tile records
@@ -986,33 +1061,11 @@ __global__ __launch_bounds__(256) void zb_walk(
                     const uint32_t rq = sync_q >= 319u ? sync_q - 319u : 0u;
                     uint32_t gt = g;
                     while (rq < offs[gt]) gt--;             // same channel: chip 0 belongs to its lane 0
-                    const uint32_t j = first_owned[gt] + (rq - offs[gt]);
-                    const uint32_t w = gt >> 6, row = gt & 63u;
-                    uint32_t lo = 0, hi2 = nt;          // last tile with cstart <= j and nc > 0 reaching j
-                    while (hi2 - lo > 1u) {
-                        const uint32_t mid = (lo + hi2) >> 1;
-                        if (TR[tr_index(w, nt, mid, 7, row)] <= j) lo = mid; else hi2 = mid;
-                    }
-                    // chip i of that tile: its window start = the tile's first window start + the steps
-                    // of the chips before it (2-bit codes step - 1, half A then half B, latest chip low)
-                    const uint32_t i = j - TR[tr_index(w, nt, lo, 7, row)];
-                    const uint32_t ncw = TR[tr_index(w, nt, lo, 6, row)];
-                    const uint32_t n_a = ncw >> 16, n_b = (ncw & 0xFFFFu) - n_a;
-                    const uint64_t ca = (uint64_t)TR[tr_index(w, nt, lo, 2, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 3, row)] << 32);
-                    const uint64_t cb = (uint64_t)TR[tr_index(w, nt, lo, 4, row)] | ((uint64_t)TR[tr_index(w, nt, lo, 5, row)] << 32);
-                    auto code_sum = [](uint64_t word, uint32_t n_in, uint32_t first) -> uint32_t {
-                        // sum of the codes of the first `first` chips of a word holding n_in chips
-                        if (first == 0u) return 0u;
-                        const uint64_t x = word >> (2u * (n_in - first));
-                        return (uint32_t)__popcll(x & 0x5555555555555555ull) + 2u * (uint32_t)__popcll(x & 0xAAAAAAAAAAAAAAAAull);
-                    };
-                    const uint32_t ia = i < n_a ? i : n_a, ib = i < n_a ? 0u : i - n_a;
-                    const uint32_t rel = TR[tr_index(w, nt, lo, 8, row)] + i + code_sum(ca, n_a, ia) + code_sum(cb, n_b, ib);
+                    const uint32_t rel = lane_chip_pos(TR, nt, gt, first_owned[gt] + (rq - offs[gt]));
                     const uint64_t cs = (uint64_t)(gt % lanes_per_slot) * core;
                     const uint64_t s0 = cs > warmup ? cs - warmup : 0ull;
                     snout_pkt* p = &stage[(size_t)g * K + n_pk];
-                    const uint32_t len = (uint32_t)s.packetlen_cnt;
-                    for (uint32_t b = len; b < 136u; b++) p->bytes[b] = 0;
+                    if (fin) { for (uint32_t b = len; b < 136u; b++) p->bytes[b] = 0; }
                     p->sample_index = first_index + s0 + rel;
                     p->proto = SNOUT_PROTO_ZIGBEE;
                     p->channel = slot_channel[slot];
@@ -1022,17 +1075,16 @@ __global__ __launch_bounds__(256) void zb_walk(
                     p->pdu_type = 0;
                     p->flags = 0;
                     p->aux = li;
-                    // FCS: CRC-16 over all but the last two bytes == those two bytes (LE)
-                    const uint32_t rx = s.b_prev | (s.b_last << 8);
-                    p->crc_ok = (uint8_t)(len >= 3u && s.c2 == rx);
+                    p->crc_ok = (uint8_t)fcs_ok;
                     // for zb_resolve (cleared by zb_emit): the chips this sink was busy with the frame
                     uint32_t* span = reinterpret_cast<uint32_t*>(&p->bytes[128]);
-                    span[0] = s.trigger;
+                    span[0] = ask ? 0xFFFFFFFFu : s.trigger;
                     span[1] = q - 1u;
+                    if (ask) req[1u + atomicAdd(&req[0], 1u)] = g;
                 }
                 n_pk++;
             }
-            enter_search(s);
+            if (fin) enter_search(s);
         }
     }
     if (exists) lane_cnt[g] = n_pk;
@@ -1051,6 +1103,193 @@ extern "C" int snout_debug_walk_stamps(unsigned long long* out, uint32_t n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_stamps), (size_t)n * 8u, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
 #endif
+
+// Frame repair (oracle_zigbee.c "Frame repair"): one thread per request.  The lane's own loop goes on from where it stood
+// at its core end (ZbLaneEnd; the filter by its recurrence from the state saved there, so every z is the value the lane
+// itself would have computed), the lane's sink from where it stood at the seam (ZbSnap + the chips of the stream between
+// its last symbol boundary and the seam), until the frame completes -- then the void record slot becomes the frame -- or
+// is given up.  Tile loop and arithmetic are zb_mm's; a few dozen waves per segment, on the tail stream.
+__global__ __launch_bounds__(64) void zb_repair(
+    const float* __restrict__ d, uint64_t d_stride, uint64_t n, uint32_t lanes_per_slot, uint32_t core, uint32_t warmup,
+    const float* __restrict__ mmse, const ZbLaneEnd* __restrict__ lane_end, const ZbSnap* __restrict__ snaps,
+    const uint32_t* __restrict__ req, const ulonglong2* __restrict__ pairs, uint64_t stream_words, uint32_t th,
+    snout_pkt* __restrict__ stage, uint32_t K, uint32_t hiprio,
+    const uint32_t* __restrict__ TR, uint32_t nt, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ first_owned,
+    const uint32_t* __restrict__ owned, const uint32_t* __restrict__ slot_total)
+{
+    __shared__ float zb[64 * kZRow];
+    __shared__ float4 tapsA[129], tapsB[129];
+    __shared__ float4 stg[2][8][64];                // two halves of 32 samples per lane, as the loads deliver them
+    if (hiprio) __builtin_amdgcn_s_setprio(3);      // a few long dependent chains beside the next segment's front end
+    const uint32_t l = threadIdx.x;
+    const uint32_t count = req[0];
+    if (blockIdx.x * 64u >= count) return;
+    for (uint32_t i = l; i < 129u; i += 64u) {
+        tapsA[i] = make_float4(mmse[i * 8u + 0u], mmse[i * 8u + 1u], mmse[i * 8u + 2u], mmse[i * 8u + 3u]);
+        tapsB[i] = make_float4(mmse[i * 8u + 4u], mmse[i * 8u + 5u], mmse[i * 8u + 6u], mmse[i * 8u + 7u]);
+    }
+    __syncthreads();
+    const uint32_t ri = blockIdx.x * 64u + l;
+    const bool active = ri < count;
+    const uint32_t g = active ? req[1u + ri] : req[1u];
+    const uint32_t li = g % lanes_per_slot, slot = g / lanes_per_slot;
+    const uint64_t core_start = (uint64_t)li * core;
+    const uint64_t s0 = core_start > warmup ? core_start - warmup : 0ull;
+    const uint32_t rce = (uint32_t)(core_start - s0) + core;
+    const uint32_t avail = n > s0 ? (uint32_t)((n - s0) < 0xFFFFFF00ull ? (n - s0) : 0xFFFFFF00ull) : 0u;
+    const ZbLaneEnd le = lane_end[g];
+    const ZbSnap sn = snaps[g];
+    SinkState s = sn.s;
+    snout_pkt* p = &stage[(size_t)g * K + sn.slot];
+    {   // the chips of the symbol the sink is in, up to the seam
+        const ulonglong2* sw = pairs + (uint64_t)slot * stream_words;
+        for (uint32_t q = sn.q_b; active && q < sn.own1; q++) {
+            const uint32_t bit = (uint32_t)(sw[q >> 6].x >> (63u - (q & 63u))) & 1u;
+            s.shift = (s.shift << 1) | bit;
+            s.chip_cnt++;
+        }
+    }
+    // Where the lane after the next takes over again (if it owns chips): from half a chip before the window start of its
+    // first owned chip the chips are that lane's, and the sink returns to the stitched stream (bounded work: one lane's
+    // samples).  Keys are lane-relative, 128 per sample + rint(128 mu).
+    const ulonglong2* sw = pairs + (uint64_t)slot * stream_words;
+    uint32_t hand_q = 0u, hand_key = 0xFFFFFFFFu;
+    if (active && li + 2u < lanes_per_slot && owned[g + 2u] != 0u && core <= (1u << 23)) {       // (lane-relative keys in 32 bits)
+        const uint64_t s0_2 = (uint64_t)(li + 2u) * core - warmup;
+        hand_q = offs[g + 2u];
+        hand_key = (uint32_t)(s0_2 + lane_chip_pos(TR, nt, g + 2u, first_owned[g + 2u]) - s0) * 128u + 64u;
+    }
+    const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
+    const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
+    const float omega_lim = omega_mid * 0.0002f;
+    double lp = le.lp;
+    float mu = le.mu, omega = le.omega, last = le.last;
+    uint32_t ii = le.ii, more = 0;
+    bool alive = active && ii >= rce && ii + 8u <= avail;
+    bool ok = false, handed = false;
+    float* zcol = &zb[l];
+    float zl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) zl[k] = 0.0f;
+    const float* d_row = d + (uint64_t)slot * d_stride + s0 + rce;      // 16-byte aligned: s0 and rce are multiples of 64
+    // The samples come half a tile (32 per lane) at a time, straight into LDS (global_load_lds_dwordx4: per-lane source
+    // address, destination = wave-uniform base + 16 lane; no registers), the next half in flight during a half's M&M steps.
+    // So the kernel stays within 96 VGPRs, which is what a SIMD has left beside the four waves of the 802.15.4
+    // channelizer's workgroup (pfb_spec<16>: 98 VGPRs, 110 KB of LDS): these waves run BESIDE the next segment's
+    // channelizer instead of keeping its workgroups off their CUs until they are done (a persistent grid with a static
+    // tile partition ends with its last workgroup: + 0.3 ms per step measured, profiles/r5_repair.md).
+    auto fetch_half = [&](uint32_t h) {
+        const float* src = d_row + 32u * h;
+#pragma unroll
+        for (uint32_t c4 = 0; c4 < 8u; c4++)
+            __builtin_amdgcn_global_load_lds(src + 4u * c4, &stg[h & 1u][c4][0], 16, 0, 0);
+    };
+    fetch_half(0u);
+    for (uint32_t half = 0; __ballot(alive) != 0ull; half++) {
+        const uint32_t r0 = rce + (half >> 1) * 64u, hb = (half & 1u) * 32u;
+        {
+#pragma unroll
+            for (int k = 0; k < 8; k++) zcol[64 * k] = zl[k];
+#pragma unroll
+            for (uint32_t c4 = 0; c4 < 8u; c4++) {
+                const float4 v4 = stg[half & 1u][c4][l];
+                const float xs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t k = 4u * c4 + j;
+                    lp = alpha * (double)xs[j] + one_minus * lp;
+                    const float z = xs[j] - (float)lp;
+                    zcol[64u * (8u + k)] = z;
+                    if (k >= 24u) zl[k - 24u] = z;
+                }
+            }
+            // the next half, into the other buffer, in flight during this half's M&M steps (the compiler drains the loads
+            // before the first read of the staging buffer; rows are padded with zeros far beyond n)
+            fetch_half(half + 1u);
+            const uint32_t staged = r0 + hb + 32u;
+            const uint32_t hi = staged < avail ? staged : avail;
+            const uint32_t zorg = r0 + hb - 8u;
+            const uint32_t lim = alive && hi >= 8u ? hi - 7u : 0u;  // windows end inside what is staged
+            while (ii < lim) {
+                // up to the next symbol boundary without looking at the sink: one exit test per chip
+                uint32_t left = 32u - (uint32_t)s.chip_cnt;
+                uint32_t sh = s.shift;
+                do {
+                    const int imu = (int)rintf(mu * 128.0f);
+                    if (ii * 128u + (uint32_t)imu + 128u >= hand_key) { handed = true; break; }
+                    const float4 ta = tapsA[imu], tb4 = tapsB[imu];
+                    const float* wv = &zcol[64u * (ii - zorg)];
+                    float acc = 0.0f;
+                    acc = __builtin_fmaf(ta.x, wv[64 * 7], acc);
+                    acc = __builtin_fmaf(ta.y, wv[64 * 6], acc);
+                    acc = __builtin_fmaf(ta.z, wv[64 * 5], acc);
+                    acc = __builtin_fmaf(ta.w, wv[64 * 4], acc);
+                    acc = __builtin_fmaf(tb4.x, wv[64 * 3], acc);
+                    acc = __builtin_fmaf(tb4.y, wv[64 * 2], acc);
+                    acc = __builtin_fmaf(tb4.z, wv[64 * 1], acc);
+                    acc = __builtin_fmaf(tb4.w, wv[0], acc);
+                    const float o = acc;
+                    const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+                    last = o;
+                    omega = omega + gain_omega * mm;
+                    {
+                        const float x = omega - omega_mid;
+                        const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+                        omega = omega_mid + c;
+                    }
+                    mu = mu + omega + gain_mu * mm;
+                    const float fl = floorf(mu);
+                    ii += fl >= 1.0f ? (uint32_t)(int)fl : 1u;
+                    mu = mu - fl;
+                    sh = (sh << 1) | (o > 0.0f ? 1u : 0u);
+                    left--;
+                } while (left != 0u && ii < lim);
+                const uint32_t took = 32u - (uint32_t)s.chip_cnt - left;
+                more += took;
+                s.shift = sh;
+                s.chip_cnt += (int)took;
+                if (handed) { alive = false; break; }
+                if (left == 0u) {                                   // a whole symbol is in
+                    const bool fin = sink_symbol(s, th, p->bytes);
+                    if (fin) { ok = true; alive = false; break; }
+                    if (s.state == 0) { alive = false; break; }     // given up (chip errors, or a length > 127)
+                }
+            }
+            if (alive && ii + 8u > avail) alive = false;            // the segment ends inside the frame
+        }
+    }
+    uint32_t end_chip = sn.own1 + more - 1u;
+    if (handed) {
+        // the rest of the frame from the stitched stream, a symbol at a time
+        const uint32_t total = slot_total[slot];
+        uint32_t q = hand_q;
+        for (;;) {
+            const uint32_t need = 32u - (uint32_t)s.chip_cnt;        // 1 .. 32 chips to the symbol boundary
+            if (q + need > total) break;                            // the stream ends inside the frame
+            const uint32_t wi = q >> 6, bo = q & 63u;
+            const uint64_t w0 = sw[wi].x, w1 = sw[wi + 1u].x;       // (the stream is padded with zero words)
+            const uint64_t x64 = bo ? (w0 << bo) | (w1 >> (64u - bo)) : w0;
+            const uint32_t bits = (uint32_t)(x64 >> (64u - need));
+            s.shift = need == 32u ? bits : ((s.shift << need) | bits);
+            q += need;
+            const bool fin = sink_symbol(s, th, p->bytes);
+            if (fin) { ok = true; end_chip = q - 1u; break; }
+            if (s.state == 0) break;
+        }
+    }
+    if (ok) {
+        const uint32_t len = (uint32_t)s.packetlen_cnt;
+        for (uint32_t b = len; b < 128u; b++) p->bytes[b] = 0;
+        p->len = (uint16_t)len;
+        const uint32_t scaled = (s.lqi / 8u) << 3;
+        p->lqi = (uint8_t)(scaled >= 256u ? 255u : scaled);
+        p->crc_ok = (uint8_t)(len >= 3u && s.c2 == (s.b_prev | (s.b_last << 8)));
+        p->flags = SNOUT_PKT_ZB_REPAIRED;
+        uint32_t* span = reinterpret_cast<uint32_t*>(&p->bytes[128]);
+        span[0] = sn.s.trigger;
+        span[1] = end_chip;
+    }
+}
 
 // The sequential rule over the candidate frames of all lanes (see the oracle, "Resolve"): in the
 // order of their SFD chips (= lane order, then time), a frame is kept iff its trigger chip lies after
@@ -1084,6 +1323,10 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
         int ns = 0;
         bool full = false;
         const uint32_t* me = reinterpret_cast<const uint32_t*>(&stage[(size_t)g * K + i].bytes[128]);
+        if (me[0] == 0xFFFFFFFFu) {     // a void slot: a frame given up behind a seam that zb_repair gave up as well
+            stage[(size_t)g * K + i].pdu_type = 1;
+            continue;
+        }
         trig[0] = me[0]; endc[0] = me[1]; ns = 1;
         uint32_t tmin = me[0];
         // walk back over the records before (g, i)
@@ -1101,7 +1344,7 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
             }
             const uint32_t* r = reinterpret_cast<const uint32_t*>(&stage[(size_t)gl * K + (uint32_t)idx].bytes[128]);
             const uint32_t rt = r[0], re = r[1];
-            if (re >= tmin) {                               // it reaches something gathered: it matters
+            if (rt != 0xFFFFFFFFu && re >= tmin) {          // (not void and) it reaches something gathered: it matters
                 if (ns == kResolveSet) { full = true; break; }
                 trig[ns] = rt; endc[ns] = re; ns++;
                 tmin = rt < tmin ? rt : tmin;
@@ -1124,6 +1367,7 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
                 const uint32_t c2 = g2 == g ? i + 1u : (lane_cnt[g2] < K ? lane_cnt[g2] : K);
                 for (uint32_t i2 = 0; i2 < c2; i2++) {
                     const uint32_t* r = reinterpret_cast<const uint32_t*>(&stage[(size_t)g2 * K + i2].bytes[128]);
+                    if (r[0] == 0xFFFFFFFFu) continue;
                     const bool drop = have && r[0] <= busy;
                     if (!drop) { have = true; busy = r[1]; }
                     if (g2 == g && i2 == i) keep_me = !drop;
@@ -1135,7 +1379,7 @@ __global__ __launch_bounds__(256) void zb_resolve(snout_pkt* __restrict__ stage,
         // SNOUT_PKT_ZB_SEAM_DISAGREED: a seam inside the frame (trigger chip < the lane's first owned chip <= last chip)
         // before which the two timing loops decided a chip of the frame differently (oracle_zigbee.c, same rule).
         // The frame's SFD chip is in this lane: seams before it are those of lanes g, g - 1, ..., seams behind it g + 1, ...
-        {
+        if (!(stage[(size_t)g * K + i].flags & SNOUT_PKT_ZB_REPAIRED)) {       // (a repaired frame has no seams)
             const uint32_t T = me[0], E = me[1];
             const uint32_t g_last = g_first + lanes_per_slot - 1u;
             bool bad = false;
@@ -1240,6 +1484,8 @@ int ZbCtx::init(uint32_t n_slots_, const uint16_t* slot_channel_, uint32_t thres
     threshold = threshold_;
     core = core_;
     warmup = warmup_;
+    if (const char* e = getenv("SNOUT_ZB_REPAIR")) repair = atoi(e) != 0;      // A/B and tests: 0 = the lanes alone
+    if (const char* e = getenv("SNOUT_ZB_TAIL_PRIO")) tail_prio = (uint32_t)atoi(e);
     if (core % 64u || warmup % 64u || warmup >= core) {
         set_last_error("zb_core (%u) and zb_warmup (%u) must be multiples of 64, warmup < core", core, warmup);
         return SNOUT_EINVAL;
@@ -1272,6 +1518,7 @@ void ZbCtx::destroy()
     d_d.release(); d_TR.release(); d_lane_out.release(); d_cand.release(); d_lane_u32.release();
     d_stream.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
     d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
+    d_lane_end.release(); d_snap.release(); d_req.release();
 }
 
 // Lane shape and the block decay factors of the IIR carry-in that depend on it.
@@ -1328,6 +1575,9 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
     if (int rc = d_S.ensure(nsb * n_slots * 8u)) return rc;
     if (int rc = d_Lblk.ensure((uint64_t)total_lanes * 8u)) return rc;
     if (int rc = d_lp_in.ensure((uint64_t)total_lanes * 8u)) return rc;
+    if (int rc = d_lane_end.ensure((uint64_t)total_lanes * sizeof(ZbLaneEnd))) return rc;
+    if (int rc = d_snap.ensure((uint64_t)total_lanes * sizeof(ZbSnap))) return rc;
+    if (int rc = d_req.ensure(((uint64_t)total_lanes + 1u) * 4u)) return rc;
     return 0;
 }
 
@@ -1342,7 +1592,7 @@ __global__ __launch_bounds__(256) void zb_clear(ulonglong2* __restrict__ p, uint
 }
 
 // a7 and the glue before it: stitched chip streams -> sinks -> per-lane records (after zb_mm).
-int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
+int ZbCtx::launch_sinks(uint64_t n, const SegBatch& segs, hipStream_t st)
 {
     uint32_t* first_owned = d_lane_u32.as<uint32_t>();
     uint32_t* owned = first_owned + total_lanes;
@@ -1357,7 +1607,7 @@ int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
     }
     hipLaunchKernelGGL(zb_stitch, dim3(tiles_per_slot, n_slots), dim3(256), 0, st,
                        d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(), lanes_per_slot, core, warmup,
-                       tiles_per_slot, first_owned, owned, tsum, seam);
+                       tiles_per_slot, first_owned, owned, tsum, seam, d_req.as<uint32_t>());
     hipLaunchKernelGGL(zb_offsets, dim3(tiles_per_slot, n_slots), dim3(256), 0, st, owned, tsum,
                        lanes_per_slot, tiles_per_slot, offs, slot_total);
     {
@@ -1377,7 +1627,14 @@ int ZbCtx::launch_sinks(const SegBatch& segs, hipStream_t st)
                        stream_words, offs, first_owned, slot_total,
                        d_TR.as<uint32_t>(), nt, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), segs, d_stage.as<snout_pkt>(), pkts_per_lane,
-                       d_lane_cnt.as<uint32_t>());
+                       d_lane_cnt.as<uint32_t>(), d_snap.as<ZbSnap>(), d_req.as<uint32_t>(), tail_prio & 1u);
+    // frame repair: at most one request per lane; the waves beyond the count return at once
+    if (repair)
+        hipLaunchKernelGGL(zb_repair, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), d_stride, n, lanes_per_slot,
+                           core, warmup, d_mmse.as<float>(), d_lane_end.as<ZbLaneEnd>(), d_snap.as<ZbSnap>(), d_req.as<uint32_t>(),
+                           reinterpret_cast<const ulonglong2*>(d_stream.as<unsigned long long>() + stream_words * n_slots),
+                           stream_words, threshold, d_stage.as<snout_pkt>(), pkts_per_lane, (tail_prio >> 1) & 1u,
+                           d_TR.as<uint32_t>(), nt, offs, first_owned, owned, slot_total);
     SNOUT_HIP(hipGetLastError());
     return 0;
 }
@@ -1401,7 +1658,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     // re-run the lanes with the tap on (rewrites identical tile records)
     hipLaunchKernelGGL(zb_mm<true>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, nullptr, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
-                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
+                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_lane_end.as<ZbLaneEnd>(), d_cand.as<uint32_t>(),
                        sz, sc, lane, (uint32_t)kSoftCap, sn);
     SNOUT_HIP(hipDeviceSynchronize());
     uint32_t nch = 0;
@@ -1452,7 +1709,7 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
                        d_lp_in.as<double>());
     hipLaunchKernelGGL(zb_mm<false>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
                        total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
-                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_cand.as<uint32_t>(),
+                       d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_lane_end.as<ZbLaneEnd>(), d_cand.as<uint32_t>(),
                        (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
     SNOUT_HIP(hipGetLastError());
     return 0;
@@ -1486,7 +1743,7 @@ int ZbCtx::enqueue_tail(uint64_t n, const SegBatch& segs_in, hipStream_t st, Res
     }
     SegBatch segs = segs_in;
     segs.slots_per_seg = seg_slots;
-    if (int rc = launch_sinks(segs, st)) return rc;
+    if (int rc = launch_sinks(n, segs, st)) return rc;
     if (time_front) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
     const uint32_t n_tiles = cdiv(total_lanes, kScanTile);
     uint32_t* lane_kept = d_lane_cnt.as<uint32_t>() + total_lanes + 1024u;
