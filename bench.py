@@ -198,8 +198,9 @@ def cpu_baseline(x_dev, workload: str, n_sample: int):
 # ------------------------------------------------------------------------------------------------
 PARITY_FIELDS = ("sample_index", "proto", "channel", "len", "crc_ok", "lqi", "pdu_type", "flags", "aux")
 # workloads whose WHOLE capture the oracle decodes in seconds to tens of seconds on the GPU box's host cores (as one
-# segment: all threads inside the channelizer, then one per bin; cfg2: the scalar loop, ~17 s per 1e9 samples)
-PARITY_FULL = ("cfg2", "cfg3", "cfg4")
+# segment: all threads inside the channelizer, then one per bin; cfg2: the scalar loop, ~17 s per 1e9 samples; zigbee1: the
+# discriminator and the lanes' loops over all threads, stitching and the sinks on one)
+PARITY_FULL = ("cfg2", "cfg3", "cfg4", "zigbee1")
 
 
 def oracle_records(x_dev, workload: str, n_sample: int):
@@ -245,6 +246,42 @@ def parity_in_run(x_dev, workload: str, n_sample: int, device, fmt: int, want=No
     return {"workload": workload, "samples": int(n_sample), "whole_capture": bool(n_sample * 2 == x_dev.numel()),
             "records": int(len(want)), "crc_ok_records": int(want["crc_ok"].sum()), "equal": True, "oracle_s": round(t_oracle, 2),
             "compared": "every record field and byte, set equality after sorting by (channel, sample_index), against the CPU oracle"}
+
+
+def lost_vs_sequential(x_dev, workload: str, n_sample: int, device, fmt: int):
+    """802.15.4 workloads: the DEFAULT decode (lanes + frame repair) against ONE sequential lane per channel -- the
+    reference's receiver (Zigbee_rx/top_block.py:67,69: one clock_recovery_mm_ff / packet_sink loop per channel) -- both on
+    the GPU, on the first n_sample samples of the capture the steps are timed on (outside the timed region).  One lane on
+    the GPU is the oracle's one lane record for record (tests/test_zigbee_gpu.py, test_fullsize_gpu.py).  Frames = FCS-ok
+    records; a frame matches if channel and bytes agree and the start is within 8 samples."""
+    import collections
+    from snout_amd.rx import SnoutRx
+    proto, n_ch, channel = WORKLOADS[workload][:3]
+    assert proto == 1
+    part = x_dev[:2 * n_sample]
+    t0 = time.perf_counter()
+    with SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt, zb_core=1 << 24) as rx:
+        one = rx.process(part).copy()
+    with SnoutRx(proto=proto, channel=channel, n_channels=n_ch, device=device.index, sample_format=fmt) as rx:
+        got = rx.process(part).copy()
+    dt = time.perf_counter() - t0
+
+    def keys(a):
+        a = a[a["crc_ok"] == 1]
+        return [(int(c), bytes(b[:l]), int(i)) for c, i, l, b in zip(a["channel"], a["sample_index"], a["len"], a["bytes"])]
+
+    def missing(A, B):
+        d = collections.defaultdict(list)
+        for c, b, i in B:
+            d[(c, b)].append(i)
+        return sum(1 for c, b, i in A if not any(abs(i - u) <= 8 for u in d.get((c, b), [])))
+    ko, kg = keys(one), keys(got)
+    lost, extra = missing(ko, kg), missing(kg, ko)
+    return {"samples": int(n_sample), "sequential_frames": len(ko), "default_frames": len(kg), "lost": lost, "extra": extra,
+            "frac_lost": lost / max(1, len(ko)), "frac_lost_plus_extra": (lost + extra) / max(1, len(ko)),
+            "repaired": int(((got["flags"] & 8) != 0).sum()), "lane_shape": "6144 / 1024 (default) + frame repair",
+            "sequential": "zb_core >= the prefix: one lane per channel on the GPU (== the oracle's, == Zigbee_rx/top_block.py:67,69)",
+            "seconds": round(dt, 2)}
 
 
 def reserved_cus(world: int, fake: int) -> int:
@@ -401,6 +438,9 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         # the whole capture where the oracle finishes it in seconds (first_sample_index 0: rank 0's own capture)
         full = parity_samples >= n and rank == 0
         res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt, got=local if full else None)
+    if proto == 1 and rank == 0 and not os.environ.get("SNOUT_BENCH_ZB_CORE"):
+        # what the default (timed) decode loses against the reference's one sequential loop
+        res["frames_lost_vs_sequential"] = lost_vs_sequential(x, name, min(n, (1 << 25) if n_ch > 1 else (1 << 24)), device, fmt)
     if keep_capture:
         return res, x
     del x
@@ -745,6 +785,8 @@ def main():
                               "stepping": "one segment at a time" if args.sync else
                                           "pipelined: record D2H of step i overlaps step i+1"},
                    "roofline": roof}
+            if "frames_lost_vs_sequential" in res:
+                out["config"]["frames_lost_vs_sequential"] = res["frames_lost_vs_sequential"]
             if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only
                 ns = int(min(args.cpu_samples or CPU_SAMPLES[headline], n))
                 out["cpu_baseline"], cpu_recs = cpu_baseline(x, headline, ns)
@@ -765,7 +807,8 @@ def main():
                                                                           else int(CPU_SAMPLES[name]) // 4))
                 others[name] = {f: r[f] for f in r if f in ("workload", "value", "unit", "ms_per_step", "steps", "kernel",
                                                   "kernel_ms", "frac", "achieved_GBps", "packets_per_gpu",
-                                                  "decoded_crc_ok_per_gpu", "min_expected_crc_ok_per_gpu", "parity_in_run")}
+                                                  "decoded_crc_ok_per_gpu", "min_expected_crc_ok_per_gpu", "parity_in_run",
+                                                  "frames_lost_vs_sequential")}
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
             r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, 0, 1, seconds=args.seconds)

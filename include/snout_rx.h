@@ -30,11 +30,14 @@
 extern "C" {
 #endif
 
-/* 2: snout_rx_pack_last_records(skip, longest_dev), SNOUT_CFG_RECORDS_ON_DEVICE, batches of up to 64 segments,
+/* 3: the 802.15.4 frame repair (snout_pkt.flags SNOUT_PKT_ZB_REPAIRED) and ONE default lane shape, 6144 / 1024, whatever the size
+ *    of a call (snout_zigbee_lane_shape ignores its argument): the records of a capture no longer depend on how it is cut
+ *    into submissions, and the default decode is within 1 % of the one sequential receiver's frames on dense traffic
+ * 2: snout_rx_pack_last_records(skip, longest_dev), SNOUT_CFG_RECORDS_ON_DEVICE, batches of up to 64 segments,
  *    snout_pkt.flags SNOUT_PKT_ZB_SEAM_DISAGREED, snout_zigbee_lane_shape (the default 802.15.4 lane shape depends on the
  *    size of the call), the bench aid moved to snout_bench.h -- a client built against version 1 fails the handshake in
  *    snout_rx_create instead of decoding a different frame set or missing a symbol */
-#define SNOUT_ABI_VERSION 2u
+#define SNOUT_ABI_VERSION 3u
 
 /* protocols (snout/core/protocols/__init__.py:2-27 names them BTLE / ZIGBEE) */
 #define SNOUT_PROTO_BTLE   0u
@@ -91,12 +94,10 @@ typedef struct snout_rx_cfg {
     uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 -> 2048           */
     uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 512;
                                  multiples of 64, warm-up < core; the timing loop needs >= 256.
-                                 BOTH 0: chosen per call by its size (snout_zigbee_lane_shape): core 4096
-                                 from 2^29 channel samples (channels x samples x segments of a batch) per
-                                 call, else 2048.  The decoded frame set is a function of the shape (DESIGN.md
-                                 section 6-3): a capture fed in one call, in segments, or in batches of other
-                                 sizes can decode differently by a fraction of a percent of its frames unless
-                                 zb_core / zb_warmup are set explicitly                                  */
+                                 BOTH 0: the default shape, core 6144 / warm-up 1024 (snout_zigbee_lane_shape),
+                                 the same for every call of every handle.  The decoded frame set is a function
+                                 of the shape and of where the calls cut the capture;
+                                 zb_core >= the call's channel samples is the reference's one sequential loop  */
     uint32_t max_hits;        /* capacity for candidate hits per call; 0 -> auto                 */
     int32_t  device;          /* HIP device ordinal; <0 -> current device                        */
     uint32_t flags;           /* SNOUT_CFG_* bits                                                */
@@ -252,10 +253,9 @@ int  snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap);
 
 /* Channel plans (a10). */
 double   snout_zigbee_center_hz(uint32_t channel);   /* 1e6*(2400+5*(ch-10)), top_block.py:56,94-96 */
-/* The 802.15.4 lane shape a handle with cfg.zb_core = cfg.zb_warmup = 0 uses for a call of `channel_samples`
- * (channels x channel samples per segment x segments of the submission): the clock recovery (clock_recovery_mm_ff, top_block.py:69) runs in lanes of
- * `core` samples that start `warmup` samples early; long calls get the longer shape.  Results are a function of the
- * shape, so a checker has to run the same one. */
+/* The 802.15.4 lane shape a handle with cfg.zb_core = cfg.zb_warmup = 0 uses: the clock recovery (clock_recovery_mm_ff,
+ * top_block.py:69) runs in lanes of `core` samples that start `warmup` samples early.  Since ABI 3 one shape for every call
+ * (`channel_samples` is ignored); results are a function of the shape, so a checker has to run the same one. */
 void     snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup);
 double   snout_btle_center_hz(uint32_t channel);     /* 37->2402, 38->2426, 39->2480, data channels */
 int32_t  snout_btle_rf_to_channel(uint32_t rf_index);/* RF k (2402+2k MHz) -> BLE channel index    */

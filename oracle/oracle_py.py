@@ -208,9 +208,10 @@ def zb_discrim(iq: np.ndarray) -> np.ndarray:
     return d[:n]
 
 
-def zb_auto_shape(total_channel_samples: int):
-    """The product's default lane shape (ZbCtx::reserve, cfg.zb_core = cfg.zb_warmup = 0): by the size of the call."""
-    return (4096, 512) if total_channel_samples >= (1 << 29) else (2048, 512)
+def zb_auto_shape(total_channel_samples: int = 0):
+    """The product's default lane shape (cfg.zb_core = cfg.zb_warmup = 0; snout_zigbee_lane_shape): one shape whatever the
+    size of the call (ABI 3)."""
+    return (6144, 1024)
 
 
 def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 0,
@@ -284,8 +285,8 @@ def wideband_segment(iq: np.ndarray, proto: int, first_sample_index: int = 0, aa
                      warmup: int = 0, cap: int = 0) -> np.ndarray:
     a = _f32(iq)
     n = a.size // 2
-    if proto == 1 and core == 0 and warmup == 0:        # the product's default: by channels x channel samples of the call
-        core, warmup = zb_auto_shape(16 * pfb_nout(n, 16))
+    if proto == 1 and core == 0 and warmup == 0:        # the product's default
+        core, warmup = zb_auto_shape()
     core, warmup = core or 2048, warmup or 512
     cap = cap or max(256, n // 128)
     out = np.zeros(cap, dtype=PKT_DTYPE)

@@ -81,16 +81,18 @@ float oracle_fast_atan2f(float y, float x)
 /* d[t] = fast_atan2f(Im(x[t] conj x[t-1]), Re(...)), x[-1] = 0 */
 void oracle_zb_discrim(const float* iq, uint64_t n, float* d)
 {
-    float pr = 0.0f, pi = 0.0f;
+    atan_init();
+    /* (pointwise: with more than one OpenMP thread set -- oracle_set_threads, never inside another parallel region's
+     * threads -- the samples are shared out; the values do not depend on it) */
+#pragma omp parallel for schedule(static)
     for (uint64_t t = 0; t < n; t++) {
+        const float pr = t ? iq[2 * t - 2] : 0.0f, pi = t ? iq[2 * t - 1] : 0.0f;
         const float ar = iq[2 * t], ai = iq[2 * t + 1];
         const float re = ar * pr + ai * pi;
         const float im = ai * pr - ar * pi;
         float a = oracle_fast_atan2f(im, re);
         if (!(fabsf(a) <= 4.0f)) a = 0.0f;      /* non-finite input: defined as 0 (stated deviation) */
         d[t] = a;
-        pr = ar;
-        pi = ai;
     }
 }
 
@@ -407,6 +409,7 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
     oracle_zb_iir_tables(w, &d64);
     const uint64_t nsb = (n + 63) / 64;
     double* S = (double*)malloc((nsb ? nsb : 1) * sizeof(double));
+#pragma omp parallel for schedule(static)
     for (uint64_t j = 0; j < nsb; j++) {
         double P[4];
         for (int p = 0; p < 4; p++) {
@@ -423,6 +426,7 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
     const double dcore = pow_rep(d64, core / 64u);
     const double dfirst = pow_rep(d64, core > warmup ? (core - warmup) / 64u : 0u);
     double* L = (double*)malloc((n_lanes ? n_lanes : 1) * sizeof(double));
+#pragma omp parallel for schedule(static)
     for (uint64_t l = 0; l < n_lanes; l++) {
         const uint64_t b0 = l == 0 ? 0 : ((uint64_t)l * core - warmup) / 64u;      /* first sub-block */
         const uint64_t b1 = ((uint64_t)(l + 1) * core - warmup) / 64u;             /* one past last   */
@@ -431,6 +435,7 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
         L[l] = a;
     }
     const uint64_t W = ((1u << 18) + core - 1) / core;
+#pragma omp parallel for schedule(static)
     for (uint64_t l = 0; l < n_lanes; l++) {
         double lp = 0.0;
         for (uint64_t i = l > W ? l - W : 0; i < l; i++) lp = (i == 0 ? dfirst : dcore) * lp + L[i];
@@ -484,9 +489,14 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
     const uint64_t n_lanes = (n + core - 1) / core;
     double* lp_in = oracle_zb_iir_carry(d, n, core, warmup, n_lanes);
     const uint64_t lane_cap = (uint64_t)core + warmup + 16;
-    uint8_t* lb = (uint8_t*)malloc(lane_cap);
-    uint64_t* lpos = (uint64_t*)malloc(lane_cap * 8);
-    uint64_t* lkey = (uint64_t*)malloc(lane_cap * 8);
+    /* the lanes' loops are independent: ZB_BLK of them at a time, shared out over the OpenMP threads when more than one is
+     * set (a single-channel capture; the wideband receivers run one channel per thread instead), then stitched in order */
+    const uint64_t ZB_BLK = lane_cap >= (1u << 20) ? 1u : ((1u << 22) / lane_cap ? (1u << 22) / lane_cap : 1u);
+    const uint64_t blk_lanes = n_lanes < ZB_BLK ? (n_lanes ? n_lanes : 1) : ZB_BLK;
+    uint8_t* LB = (uint8_t*)malloc(lane_cap * blk_lanes);
+    uint64_t* LPOS = (uint64_t*)malloc(lane_cap * blk_lanes * 8);
+    uint64_t* LKEY = (uint64_t*)malloc(lane_cap * blk_lanes * 8);
+    uint64_t* NC = (uint64_t*)malloc(blk_lanes * 8);
     uint8_t* sb = (uint8_t*)malloc(n + 16 + 4096);      /* stitched stream: at most one chip per sample */
     uint64_t* spos = (uint64_t*)malloc((n + 16 + 4096) * 8);
     uint64_t* o = (uint64_t*)malloc((n_lanes + 1) * 8); /* stream offset of every lane's first owned chip */
@@ -496,7 +506,17 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
     uint64_t E = 0, prev_nc = 0, prev_hist = 0;
     for (uint64_t l = 0; l < n_lanes; l++) {
         const uint64_t cs = l * core, ce = cs + core;
-        const uint64_t nc = mm_lane(d, n, cs, ce - cs, warmup, lp_in[l], lb, lpos, lkey, NULL, NULL, 0, &ends[l]);
+        if (l % blk_lanes == 0) {
+            const uint64_t nb = n_lanes - l < blk_lanes ? n_lanes - l : blk_lanes;
+#pragma omp parallel for schedule(dynamic, 4)
+            for (uint64_t i = 0; i < nb; i++)
+                NC[i] = mm_lane(d, n, (l + i) * core, core, warmup, lp_in[l + i], LB + i * lane_cap, LPOS + i * lane_cap,
+                                LKEY + i * lane_cap, NULL, NULL, 0, &ends[l + i]);
+        }
+        const uint8_t* lb = LB + (l % blk_lanes) * lane_cap;
+        const uint64_t* lpos = LPOS + (l % blk_lanes) * lane_cap;
+        const uint64_t* lkey = LKEY + (l % blk_lanes) * lane_cap;
+        const uint64_t nc = NC[l % blk_lanes];
         uint64_t f = 0;
         seam[l] = l ? 0xFFFFFFFFFFFFull : 0;                        /* no comparison made: nothing verified */
         if (l > 0) {
@@ -618,7 +638,7 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
             if (done) enter_search(&s);
         }
     }
-    free(ends); free(seam); free(o); free(spos); free(sb); free(lkey); free(lpos); free(lb); free(lp_in);
+    free(ends); free(seam); free(o); free(spos); free(sb); free(NC); free(LKEY); free(LPOS); free(LB); free(lp_in);
 }
 
 int oracle_zigbee_segment(const float* iq, uint64_t n, uint64_t first_index, uint32_t channel,

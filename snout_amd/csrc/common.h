@@ -210,7 +210,6 @@ struct ZbCtx {
     uint64_t stream_words = 0;                          // u64 words of one channel's chip stream
     uint64_t d_stride = 0;                              // floats per channel row of the discriminator output
     bool overflow = false;
-    bool auto_shape = false;        // lane core / warm-up chosen per call by its size (cfg.zb_core = cfg.zb_warmup = 0)
     void set_shape(uint32_t core, uint32_t warmup);
     DevBuf d_atan, d_mmse, d_slot_channel, d_stage, d_lane_cnt, d_soft;
     // discriminator output rows, tile records, per-lane stitch inputs, candidate keys,

@@ -107,13 +107,13 @@ int snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap)
 
 void snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup)
 {
-    // The long shape has half the seams (frames lost against one sequential lane on a noisy 16-channel capture: 5 of 731
-    // with 2048 / 512, 1 with 4096 / 512 or 4096 / 1024: profiles/r3_lane_residual.md) and redoes an eighth instead of a
-    // quarter of the clock recovery as warm-up -- but it needs about 2^29 channel samples to fill the GPU (1e9 samples,
-    // one channel: 4.66 against 5.02 ms; 16 x 4e7: equal; 16 x 1.7e7: 1.73 against 1.60 ms).
-    const bool big = channel_samples >= (1ull << 29);
-    if (core) *core = big ? 4096u : 2048u;
-    if (warmup) *warmup = 512u;
+    // One shape for every call since ABI 3 (round 5): what a capture decodes to must not depend on how it is cut into
+    // submissions.  6144 / 1024 with the frame repair loses 0.4 % of the one sequential loop's frames on cfg #4's dense
+    // traffic and reports 0.6 % that it misses (profiles/r5_lane_fidelity.md); longer cores leave the GPU fewer lanes than
+    // it has SIMDs (8192 / 1024: the same fidelity within the error, + 10 % step time), shorter ones hand over more often.
+    (void)channel_samples;
+    if (core) *core = 6144u;
+    if (warmup) *warmup = 1024u;
 }
 
 double snout_zigbee_center_hz(uint32_t channel)

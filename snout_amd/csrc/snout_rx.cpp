@@ -323,7 +323,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     if (c.crc_init == 0) c.crc_init = 0x555555u;
     if (c.chip_threshold == 0) c.chip_threshold = 10;
     if (c.taps_per_branch == 0) c.taps_per_branch = 16;
-    const bool zb_auto = c.zb_core == 0 && c.zb_warmup == 0;     // lane shape by the size of each call (ZbCtx::reserve)
+    if (c.zb_core == 0 && c.zb_warmup == 0) snout_zigbee_lane_shape(0, &c.zb_core, &c.zb_warmup);   // the default shape, fixed per handle
     if (c.zb_core == 0) c.zb_core = 2048;
     if (c.zb_warmup == 0) c.zb_warmup = 512;
     if (c.n_channels == 0) c.n_channels = 1;
@@ -378,7 +378,6 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
                        "Zigbee: 1 or 16)", c.proto, c.n_channels);
         goto fail;
     }
-    h->zb.auto_shape = h->zb2.auto_shape = h->zb3.auto_shape = zb_auto;
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
     for (int k = 0; k < 3; k++) {
         if (hipEventCreate(&h->ws_free[k]) != hipSuccess) { rc = SNOUT_EHIP; goto fail; }

@@ -1536,15 +1536,6 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
 {
     if (segs == 0 || segs > batch_cap) { set_last_error("batch of %u segments (handle created for %u)", segs, batch_cap); return SNOUT_EINVAL; }
     n_slots = seg_slots * segs;                     // slot = (segment of the batch, channel)
-    if (auto_shape) {
-        // cfg.zb_core = cfg.zb_warmup = 0: by the size of the call (snout_zigbee_lane_shape; oracle_py.zb_auto_shape mirrors it)
-        uint32_t c_ = 0, w_ = 0;
-        // by everything the submission carries (channels x samples x segments of a batch): the long shape needs that many lanes
-        // to fill the GPU, and it is the more faithful one (half the seams).  A batch whose total crosses the threshold
-        // therefore decodes with another shape than its segments would one by one; cfg.zb_core pins it.
-        snout_zigbee_lane_shape(n * (uint64_t)seg_slots * segs, &c_, &w_);
-        set_shape(c_, w_);
-    }
     lanes_per_slot = cdiv(n, core);
     total_lanes = lanes_per_slot * n_slots;
     n_waves = cdiv(total_lanes, 64);

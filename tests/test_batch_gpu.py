@@ -232,35 +232,36 @@ def test_records_stay_on_the_device():
         assert rx.process(cap, first_sample_index=5).tobytes() == want.tobytes()
 
 
-def test_the_default_lane_shape_goes_by_the_whole_submission(oracle):
-    """cfg.zb_core = cfg.zb_warmup = 0: the 802.15.4 lane shape follows the channel samples of the whole SUBMISSION
-    (channels x samples x segments).  33 segments of 2^23 input samples are more than 2^29 channel samples: the batch decodes with
-    core 4096 (what the oracle decodes with that shape set explicitly), one such segment alone with core 2048 -- the frame
-    sets differ slightly, by design; an explicit zb_core pins the shape for both."""
+def test_the_default_lane_shape_is_the_same_for_a_batch_and_its_segments(oracle):
+    """cfg.zb_core = cfg.zb_warmup = 0: ONE default lane shape (6144 / 1024, snout_zigbee_lane_shape) whatever a submission
+    carries (round 4 chose the shape by channels x samples x segments of the submission, so the last, shorter
+    batch of a capture -- or another world size -- decoded another frame set).  33 segments of 2^23 input samples in one
+    batch decode what each decodes alone, which is what the oracle decodes with the default shape; an explicit zb_core
+    still pins another shape for both."""
     import torch
     from snout_amd import synth
     from snout_amd.rx import SnoutRx
     n_in = 1 << 23
     x, truth = synth.wideband_capture(1, n_in, seed=91, sigma=0.05, mean_gap=9000.0)
     cap = torch.from_numpy(np.ascontiguousarray(x[:n_in]).view(np.float32)).cuda()
-    count = 33          # 33 x 16 x 1 048 545 channel samples: just above 2^29 (32 are just below)
+    count = 33          # 33 x 16 x 1 048 545 channel samples: above round 4's threshold of 2^29 (one segment is below)
     firsts = [1000 * k for k in range(count)]
     oracle.set_threads(oracle.hw_threads())
     try:
-        want_long = oracle.wideband_segment(x[:n_in], 1, core=4096, warmup=512)
-        want_short = oracle.wideband_segment(x[:n_in], 1)
+        want = oracle.wideband_segment(x[:n_in], 1)
+        want_short = oracle.wideband_segment(x[:n_in], 1, core=2048, warmup=512)
     finally:
         oracle.set_threads(1)
-    assert len(want_long) > 300
+    assert len(want) > 300 and oracle.zb_auto_shape() == (6144, 1024)
     with SnoutRx(proto=1, n_channels=16, batch_segments=count) as rx:
         rx.submit_batch([cap] * count, firsts)
         got = rx.collect()
-        assert len(got) == count * len(want_long)
+        assert len(got) == count * len(want)
         for k in (0, 13, count - 1):
-            seg = got[k * len(want_long):(k + 1) * len(want_long)].copy()
+            seg = got[k * len(want):(k + 1) * len(want)].copy()
             seg["sample_index"] -= np.uint64(firsts[k])
-            assert seg.tobytes() == want_long.tobytes()
-        assert rx.process(cap).tobytes() == want_short.tobytes()          # one segment alone: the short shape
+            assert seg.tobytes() == want.tobytes()
+        assert rx.process(cap).tobytes() == want.tobytes()          # one segment alone: the same shape, the same records
     with SnoutRx(proto=1, n_channels=16, batch_segments=count, zb_core=2048, zb_warmup=512) as rx:
         rx.submit_batch([cap] * count, firsts)
         got = rx.collect()
