@@ -480,7 +480,7 @@ def traffic_from_profiles(workload: str, kernel: str, n: int):
 # ------------------------------------------------------------------------------------------------
 # cfg #5: both wideband scans concurrently, sharded in 2^24-sample segments
 # ------------------------------------------------------------------------------------------------
-def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: float = 10.0, group=None):
+def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: float = 10.0, group=None, parity: bool = False):
     import torch
     import torch.distributed as dist
     from snout_amd import dist as sdist
@@ -656,6 +656,37 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
                                  "%d copies of its own records per step (sample_index shifted per copy), as it will at N = %d" % (fake, fake)}
         res["achieved_GBps"] = res["algorithmic_bytes"] / (res["ms_per_step"] * 1e-3) / 1e9
         res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
+        if parity and world == 1 and not fake:
+            # cfg #5 against the oracle AS cfg #5 -- rank 0's de-duplicated records of the last step == what
+            # the CPU oracle decodes from the same segments (same cuts, overlaps, pre-roll, lane shape), de-duplicated by the
+            # host statement of the same rule (snout_amd.dist.dedup_records), every field and byte; outside the timed region.
+            # What the consumer keeps: snout/core/message.py:226 (CRC0 lines), snout/util/zigbee.py:194-202 (every PDU).
+            from oracle import oracle_py
+            t_or = time.perf_counter()
+            oracle_py.set_threads(oracle_py.hw_threads())
+            try:
+                res["parity_in_run"] = {}
+                for name, sc, src, got, tol in (("btle", sb, srcb, rb, 0), ("zigbee", sz, srcz, rz, 8 * 64 + 8)):
+                    parts = []
+                    for j, (a, b) in enumerate(sc._segs):
+                        host = src(a, b).cpu().numpy()
+                        rec = oracle_py.wideband_segment(host, proto=sc.proto, first_sample_index=a // sc.decim)
+                        own = (j * sc.seg_len) // sc.decim if (j and sc.preroll) else 0       # world 1: local segment j = global j
+                        parts.append(rec[rec["sample_index"] >= own] if own else rec)
+                    want = sdist.dedup_records(np.concatenate(parts), tol=tol)
+                    have = sdist.widen_records(np.asarray(got))
+                    equal = len(want) == len(have) and all(np.array_equal(want[f], have[f]) for f in PARITY_FIELDS) \
+                        and np.array_equal(want["bytes"], have["bytes"])
+                    assert equal, f"cfg5 {name}: rank 0's records of one step differ from the oracle's ({len(have)} vs {len(want)})"
+                    res["parity_in_run"][name] = {"segments": len(sc._segs), "records": int(len(want)), "crc_ok_records": int(want["crc_ok"].sum()),
+                                                  "equal": True}
+                res["parity_in_run"]["oracle_s"] = round(time.perf_counter() - t_or, 2)
+                # the 802.15.4 scan's traffic is cfg #4's: what the timed (default) decode loses against one sequential lane
+                res["frames_lost_vs_sequential"] = lost_vs_sequential(xz, "cfg4", min(1 << 25, xz.numel() // 2), device, 0)
+                res["parity_in_run"]["compared"] = ("rank 0's sorted, de-duplicated records of the last timed step against the CPU oracle on the same "
+                                                    "segments + dist.dedup_records: every record field and byte")
+            finally:
+                oracle_py.set_threads(1)
     sb.close()
     sz.close()
     del xb, xz, caps
@@ -665,10 +696,45 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
 
 CFG5_FIELDS = ("workload", "value", "unit", "ms_per_step", "steps", "segments_per_gpu", "segments_per_submission", "records_on_rank0",
                "decoded_crc_ok", "min_expected_crc_ok", "frac", "value_per_gpu", "collective", "ranks_in_collective", "achieved_GBps",
-               "sharding", "fake_world", "reserved_cus")
+               "sharding", "fake_world", "reserved_cus", "parity_in_run", "frames_lost_vs_sequential")
 
 
 # ------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments>` as a child process,
+    stream its output, print rank 0's JSON line as the one and last JSON line of stdout.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SNOUT_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch                            # device_count() does not initialise the GPU (no HIP context in the parent)
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py --gpus {n}: {have} GPU(s) visible; one rank per GPU needs {n} "
+                  "(SNOUT_BENCH_BACKEND=gloo shares devices between ranks: a debugging aid, not a measurement)", file=sys.stderr)
+            return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    last_json = None
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            last_json = line                    # held back: printed once, as the last line
+            continue
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if last_json is not None:
+        sys.stdout.write(last_json if last_json.endswith("\n") else last_json + "\n")    # the contract: ONE JSON line, last on stdout
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -693,14 +759,21 @@ def main():
                     help="one segment at a time (no submit/collect pipelining); for profiling")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself (what replaces the sequential hop of
+        # snout/core/radio.py:415): this process has touched no GPU, so it starts the N ranks as a CHILD (never an exec),
+        # passes their output through, prints rank 0's JSON once more as ITS last line of stdout and exits with their code
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` by itself, or "
+                         "torch.distributed.run --nproc-per-node N bench.py --gpus N")
     # one rank per GPU; SNOUT_BENCH_BACKEND=gloo lets the multi-rank code path be exercised on a box
     # with fewer GPUs than ranks (ranks then share devices; a debugging aid, not a measurement)
     backend = os.environ.get("SNOUT_BENCH_BACKEND", "nccl")
@@ -737,7 +810,7 @@ def main():
     out = None
 
     if headline == "cfg5":
-        r5 = run_cfg5(args.steps, args.warmup, device, rank, world, seconds=args.seconds)
+        r5 = run_cfg5(args.steps, args.warmup, device, rank, world, seconds=args.seconds, parity=not args.no_cpu)
         if rank == 0:
             out = {"metric": METRIC, "value": r5["value"], "unit": "Msamples/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": r5["ms_per_step"],
@@ -811,7 +884,7 @@ def main():
                                                   "frames_lost_vs_sequential")}
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
-            r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, 0, 1, seconds=args.seconds)
+            r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, 0, 1, seconds=args.seconds, parity=not args.no_cpu)
             others["cfg5"] = {f: r5[f] for f in CFG5_FIELDS if f in r5}
             others["cfg5"]["note"] = "BASELINE.json configs[4] on one GPU; `--gpus N` carries its N-rank point the same way"
             out["other_workloads"] = others

@@ -85,6 +85,11 @@ def _source(proto, iq, synthetic, channels, seconds, fmt="cf32", wideband=False,
     if wideband or sharded:
         pid = 0 if proto == "btle" else 1
         if iq:
+            import os
+            import stat
+            if iq == "-" or not stat.S_ISREG(os.stat(iq).st_mode):
+                raise click.UsageError("--wideband / --sharded read a capture FILE (live streams -- '-', a FIFO, a device -- "
+                                       "are implemented for the single-channel scans only)")
             return WidebandSource(iq, pid, FORMATS[fmt], segment=segment, sharded=sharded, batch=batch)
         if not synthetic:
             raise click.UsageError("give --iq FILE or --synthetic (no live SDR in this build)")
@@ -185,8 +190,8 @@ def zigbee():
 @_scan_options
 @click.option("--udp", is_flag=True, help="send RFtap datagrams to 127.0.0.1:52002 (scapy-radio)")
 @click.option("--lane-core", type=int, default=0,
-              help="clock-recovery lane length in channel samples (multiple of 64; 0: by the size of the call). The reference's "
-                   "receiver is ONE sequential loop: longer lanes and warm-ups decode closer to it, slower (DESIGN.md 6-3)")
+              help="clock-recovery lane length in channel samples (multiple of 64; 0: the default shape, 6144 with warm-up 1024). The "
+                   "reference's receiver is ONE sequential loop: a lane at least as long as the capture is that loop (DESIGN.md 6-3)")
 @click.option("--lane-warmup", type=int, default=0, help="samples a lane's timing loop starts before its core (multiple of 64; 0: 512)")
 def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, batch, filename, iq, fmt, synthetic,
                 seconds, udp, lane_core, lane_warmup):

@@ -197,7 +197,10 @@ class AsyncRecordGather:
     that nothing de-duplicates away) and rank 0 sorts, de-duplicates and downloads F blocks, as it will at N = F.
     """
 
-    HDR = 32        # header bytes per rank: count, longest record (host appends), longest record (device appends), spare
+    HDR = 32        # header bytes per rank: count, longest record (host appends), longest record (device appends), launch ticket
+    AHEAD = 4       # exchanges a rank may have opened behind the oldest unfinished one
+    _gathers = {}   # process group -> gathers created on it so far (their creation index is part of the ticket)
+    _tickets = {}   # process group -> launches so far
 
     def __init__(self, device=None, group=None, width: int = REC, dedup_tol: Optional[int] = None,
                  cap: int = 0, fake_world: int = 0, prealloc: int = 0):
@@ -223,6 +226,17 @@ class AsyncRecordGather:
         self.fake = int(fake_world) if (fake_world and fake_world > 1 and self.world == 1) else 0
         self.blocks = self.fake or self.world       # record blocks rank 0 holds after an exchange
         self.cap = int(cap)             # capacity new exchanges are sized for (0: agreed at the first launch)
+        # The capacity of an exchange is a function of its INDEX, not of when begin() happens to run: finish() of exchange j
+        # may grow the capacity (every rank sees the same headers and computes the same number), and a rank may by then have
+        # opened up to AHEAD exchanges behind j while another has not -- so the grown capacity holds from exchange
+        # j + AHEAD + 1 on, on every rank alike (sized at call time, the send / receive sizes of one exchange
+        # could differ between ranks: a hang).  begin() refuses to run further ahead than that.
+        self.n_begun = self.n_finished = 0
+        self.cap_from = []              # [(first exchange index, capacity)], ascending
+        # exchanges of every gather that shares a process group must be launched in the same order on every rank: each launch
+        # takes the group's next ticket, the ticket travels in the header and finish() compares it across the ranks
+        self.gid = AsyncRecordGather._gathers.get(id(group) if group is not None else 0, 0)
+        AsyncRecordGather._gathers[id(group) if group is not None else 0] = self.gid + 1
         self.expect = None              # record counts of the last finished exchange: what the next download is sized for
         self.pool = []                  # finished slots, oldest first: reused once another has finished (views stay valid until then)
         self.cur = None                 # the open exchange (appends go here)
@@ -251,7 +265,7 @@ class AsyncRecordGather:
         ev = torch.cuda.Event() if self.on_gpu else None
         up = torch.cuda.Event() if self.on_gpu else None
         hdr2 = torch.zeros((B, 4), dtype=torch.int64, pin_memory=pin)                # every rank's header, downloaded
-        hsend = torch.zeros(2, dtype=torch.int64, pin_memory=pin)                    # this rank's (count, longest on host), staged
+        hsend = torch.zeros(4, dtype=torch.int64, pin_memory=pin)                    # this rank's (count, longest on host, launch ticket), staged
         work = out = n_keep = None
         if self.rank == 0 and self.dedup_tol is not None and self._native():
             # the library's sort + duplicate removal (snout_records_dedup): its scratch, its output, its count
@@ -288,6 +302,11 @@ class AsyncRecordGather:
     def _ctx(self):
         return self.torch.cuda.stream(self.stream) if self.on_gpu else _null_ctx()
 
+    @property
+    def cap_scheduled(self) -> int:
+        """The largest capacity agreed so far (in force now or from a later exchange on)."""
+        return max([self.cap] + [c for _, c in self.cap_from])
+
     # ---- one exchange --------------------------------------------------------------------------
     def begin(self, n_hint: int = 0) -> None:
         """Open an exchange.  The first one agrees the capacity (collective: 1.25x the largest
@@ -296,16 +315,26 @@ class AsyncRecordGather:
         if self.cap == 0:
             m = self._agree(int(n_hint))
             self.cap = m + m // 4 + 1024
+        if self.n_begun - self.n_finished > self.AHEAD:
+            raise RuntimeError(f"{self.n_begun - self.n_finished} exchanges opened and not finished: finish() one first")
+        k = self.n_begun
+        self.n_begun += 1
+        cap = self.cap                  # the capacity of exchange k: the last growth that has come into force
+        for first, c in self.cap_from:
+            if first <= k:
+                cap = max(cap, c)
+        self.cap_from = [(f, c) for f, c in self.cap_from if f > k]
+        self.cap = cap
         slot = None
-        if self.spare and self.spare[-1]["cap"] >= self.cap:
+        if self.spare and self.spare[-1]["cap"] == cap:
             slot = self.spare.pop()
         elif len(self.pool) >= 2:         # the oldest finished slot: another exchange has finished since (its views were valid until then)
             slot = self.pool.pop(0)
-            if slot["cap"] < self.cap:
+            if slot["cap"] != cap:
                 slot = None
         if slot is None:
-            slot = self._make_slot(self.cap)
-        slot["fill"], slot["n"], slot["rest"], slot["wide"] = 0, 0, [], 0
+            slot = self._make_slot(cap)
+        slot["fill"], slot["n"], slot["rest"], slot["wide"], slot["index"] = 0, 0, [], 0, k
         with self._ctx():
             slot["head"].zero_()            # [2]: raised by the pack kernels of device-side appends
         self.cur = slot
@@ -376,7 +405,7 @@ class AsyncRecordGather:
             # header: true count and longest record appended on the host.  Staged in pinned memory (an asynchronous copy);
             # the slot is reused only after finish() has waited for this exchange's event.
             slot["hsend"][0], slot["hsend"][1] = slot["n"], slot["wide"]
-            slot["head"][:2].copy_(slot["hsend"], non_blocking=True)
+            slot["head"][:2].copy_(slot["hsend"][:2], non_blocking=True)
             if self.on_gpu:
                 slot["up"].record(self.stream)       # the callers' record buffers may be reused after this
         self.closed.append(slot)
@@ -391,8 +420,13 @@ class AsyncRecordGather:
             raise RuntimeError("two gathers in flight: finish() one first")
         slot = self.closed.pop(0)
         W, cap, B = self.width, slot["cap"], self.blocks
+        gkey = id(self.group) if self.group is not None else 0
+        ticket = AsyncRecordGather._tickets.get(gkey, 0)
+        AsyncRecordGather._tickets[gkey] = ticket + 1
         with self._ctx():
             heads = slot["heads"]
+            slot["hsend"][2] = (self.gid << 40) | ticket         # (its own staging word: close()'s copy may still be reading the others)
+            slot["head"][3:4].copy_(slot["hsend"][2:3], non_blocking=True)
             if self.collective:
                 self.dist.all_gather_into_tensor(heads[:self.world].view(-1), slot["head"], group=self.group)
                 if self.to_root:
@@ -476,7 +510,8 @@ class AsyncRecordGather:
             self.dist.all_gather_into_tensor(recv, send, group=self.group)
         else:
             recv.copy_(send)
-        self.cap = max(self.cap, int(max(counts)) + int(max(counts)) // 4 + 1024)     # same on every rank
+        # same number on every rank; in force from the first exchange no rank can have opened yet (see __init__)
+        self.cap_from.append((slot["index"] + self.AHEAD + 1, int(max(counts)) + int(max(counts)) // 4 + 1024))
         if self.rank != 0:
             return None
         host = recv.cpu().numpy().reshape(self.world, over * W)
@@ -493,11 +528,16 @@ class AsyncRecordGather:
             return None
         slot = self.inflight.pop(0)
         self.pool.append(slot)
+        self.n_finished += 1
         if self.on_gpu:
             slot["ev"].synchronize()
         W, cap, B = self.width, slot["cap"], self.blocks
         h2 = slot["hdr2"].numpy()
         counts = [int(c) for c in h2[:self.world, 0]]
+        tickets = {int(t) for t in h2[:self.world, 3]}
+        if len(tickets) != 1:           # every rank sees the same headers: every rank raises
+            raise RuntimeError("the gathers of this process group were launched in different orders on different ranks "
+                               f"(tickets {sorted(tickets)}): launch every gather's exchanges in the same order everywhere")
         widest = int(h2[:self.world, 1:3].max())
         if widest > W - 24:             # every rank sees the same headers: every rank raises, none is left in a collective
             raise ValueError(f"a rank appended a record of {widest} bytes: it does not fit the {W}-byte wire format")

@@ -252,6 +252,8 @@ def _pipelined_segments(proto: int, channel: int, x: np.ndarray, sample_format: 
 
     def source(a, b):
         chunk = np.ascontiguousarray(x[a:b])
+        if not chunk.flags.writeable:           # a read-only memmap: torch wants a buffer it may write to (it never does)
+            chunk = chunk.copy()
         if chunk.dtype == np.complex64:
             chunk = chunk.view(np.float32)
         return torch.from_numpy(chunk.reshape(-1)).to(dev)

@@ -106,10 +106,11 @@ class ShardedScan:
         for k, sub in enumerate(subs):
             self._jobs.append(dict(segs=[self._segs[i] for i in sub], own=[own_from[i] for i in sub], source=source, sink=sink,
                                    on_first=on_first if k == 0 else None, on_last=on_last if k == len(subs) - 1 else None))
-        if not subs and on_first is not None:       # nothing to do for this rank: the exchange still opens and closes
-            on_first()
-        if not subs and on_last is not None:
-            on_last()
+        if not subs and (on_first is not None or on_last is not None):
+            # nothing to do for this rank: the exchange still opens and closes -- in its turn, behind the submissions of
+            # the capture before (an empty job carries the callbacks; called here they would open the next exchange while
+            # the previous one is still being filled)
+            self._jobs.append(dict(segs=[], own=[], source=source, sink=sink, on_first=on_first, on_last=on_last))
 
     def active(self) -> bool:
         return self._streams is not None and bool(self._jobs or self._flight)
@@ -129,6 +130,11 @@ class ShardedScan:
         t0 = time.perf_counter() if tr is not None else 0.0
         if (not block and n_fl >= H and self.rxs[self._done % H].ready()):
             pass                                    # results are waiting: take them before queueing more
+        elif self._jobs and not self._jobs[0]["segs"]:
+            # an empty job (a capture without a segment for this rank): no handle, no slot; it takes its turn in the
+            # collection order
+            self._flight.append(self._jobs.popleft())
+            return True
         elif self._jobs and n_fl < self.depth * H:
             j = self._next
             job = self._jobs.popleft()
@@ -153,6 +159,13 @@ class ShardedScan:
             if tr is not None:
                 tr.append(("submit%d x%d" % (self.proto, len(xs)), time.perf_counter() - t0))
             return True
+        if n_fl and not self._flight[0]["segs"]:
+            job = self._flight.popleft()
+            if job["on_first"] is not None:
+                job["on_first"]()
+            if job["on_last"] is not None:
+                job["on_last"]()
+            return True
         if n_fl:
             j = self._done
             rx = self.rxs[j % H]
@@ -171,6 +184,9 @@ class ShardedScan:
                     ev.record(sink.stream)
                     self._appended[j % H] = ev
             else:
+                if getattr(rx, "records_on_device", False):
+                    raise RuntimeError("this scan keeps its records on the device (records_on_device=True): start() it with a "
+                                       "sink (an AsyncRecordGather on the GPU) -- run() / run_concurrent() collect to the host")
                 rec = rx.collect()
                 if own:
                     rec = rec[rec["sample_index"] >= own]

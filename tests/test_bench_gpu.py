@@ -66,6 +66,11 @@ def test_default_run_carries_every_workload():
         assert w["kernel"] == kern and w["value"] > 0 and w["kernel_ms"] > 0 and 0 < w["frac"] < 1
         assert w["decoded_crc_ok_per_gpu"] >= w["min_expected_crc_ok_per_gpu"] > 0
         assert w["parity_in_run"]["equal"] is True and w["parity_in_run"]["records"] > 100
+    # the 802.15.4 steps are timed on the faithful default: what it loses against one sequential lane per channel, in-run
+    for name, prefix in (("cfg4", 1 << 25), ("zigbee1", 1 << 24)):
+        fl = ow[name]["frames_lost_vs_sequential"]
+        assert fl["samples"] == prefix and fl["sequential_frames"] > 300 and fl["frac_lost"] <= 0.01 and fl["frac_lost_plus_extra"] <= 0.015
+    assert ow["zigbee1"]["parity_in_run"]["samples"] == 1000000000 and ow["zigbee1"]["parity_in_run"]["whole_capture"] is True
     # the WHOLE 8e8-sample capture against the oracle (one segment, every host thread), and the timed CPU leg's prefix
     pr = d["parity_in_run"]
     assert pr["equal"] is True and pr["samples"] == 800000000 and pr["whole_capture"] is True and pr["records"] == d["config"]["packets_per_gpu"]
@@ -117,6 +122,43 @@ def test_two_ranks_default_line_is_the_headline_workload_on_every_rank():
     assert d["roofline"]["kernel"] == "pfb_spec40" and 0 < d["roofline"]["frac"] < 1
     o5 = d["other_workloads"]["cfg5"]
     assert o5["workload"].startswith("cfg5") and o5["decoded_crc_ok"] >= o5["min_expected_crc_ok"] > 0 and o5["value"] > 0
+
+
+def test_cfg5_is_checked_against_the_oracle_as_cfg5():
+    """`--workload cfg5` at reduced size (1 s of each band: 5 + 2 segments of 2^24 samples) -- rank 0's sorted,
+    de-duplicated records of one step equal what the CPU oracle decodes from the same overlapping segments (+ the host statement
+    of the de-duplication rule), every field and byte; the bench asserts it in-run and reports it."""
+    d = _bench("--workload", "cfg5", "--steps", "2", "--warmup", "1", "--seconds", "1")
+    pr = d["config"]["parity_in_run"]
+    assert pr["btle"]["equal"] is True and pr["zigbee"]["equal"] is True
+    assert pr["btle"]["segments"] == 5 and pr["zigbee"]["segments"] == 2
+    assert pr["btle"]["records"] + pr["zigbee"]["records"] == d["config"]["records_on_rank0"] > 1000
+    fl = d["config"]["frames_lost_vs_sequential"]
+    assert fl["sequential_frames"] > 300 and fl["frac_lost"] <= 0.01
+
+
+def test_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` as a plain command (no torchrun around it, WORLD_SIZE unset) starts
+    its ranks as a child process and prints rank 0's JSON as the one JSON line, last on stdout.  Two ranks over gloo on the
+    box's one GPU; the exchange is the real one (32-byte headers all_gather + records to rank 0)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SNOUT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--samples", "4e7", "--no-others"], capture_output=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = _last_json(r.stdout)
+    assert r.stdout.decode().rstrip().splitlines()[-1].startswith("{")         # the JSON is the last line
+    c = d["config"]
+    assert KEYS <= set(d) and d["metric"] == METRIC and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert c["ranks_in_collective"] == 2 and c["workload"].startswith("cfg3")
+    # rank 0 holds every rank's records of the last step: the sum of what the two ranks decode (bench.py asserts equality
+    # with the all-reduced count inside the run; both ranks decode >= the expected minimum)
+    assert c["records_on_rank0_last_step"] >= 2 * c["min_expected_crc_ok_per_gpu"] > 0
+    # on the RCCL backend one rank per GPU is required: asking for more GPUs than the box has fails fast, before any rank starts
+    env.pop("SNOUT_BENCH_BACKEND")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True,
+                       timeout=300, env=env)
+    assert r.returncode == 2 and b"GPU(s) visible" in r.stderr and not r.stdout.strip()
 
 
 def test_two_ranks_single_workload_over_gloo():

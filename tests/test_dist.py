@@ -186,7 +186,7 @@ def _worker_overflow(rank, world, port, q):
                 outs.append(g.finish())
             if rank == 0:
                 q.put((dedup, [(len(o), sorted(set(o["channel"].tolist())),
-                               int(o["sample_index"].min()), int(o["sample_index"].max())) for o in outs], g.cap))
+                               int(o["sample_index"].min()), int(o["sample_index"].max())) for o in outs], g.cap_scheduled))
             else:
                 assert all(o is None for o in outs)
         dist.barrier()
@@ -215,7 +215,119 @@ def test_gather_overflow_is_a_collective_decision_gloo_world2():
         for step, (n, chans, lo, hi) in enumerate(outs):
             assert n == sum(sizes[step]) and chans == [37, 38], (dedup, step, n)
             assert lo == 100000 * step and hi == 100000 * step + max(sizes[step]) - 1
-        assert cap >= 5200                         # the capacity grew with the traffic, on every rank alike
+        assert cap >= 5200                         # the capacity grows with the traffic, on every rank alike (from a later exchange on)
+
+
+def _worker_overflow_straddle(rank, world, port, q):
+    """ADVICE r4: rank 0 has already OPENED exchanges 1 and 2 when exchange 0 overflows and its finish() grows the capacity;
+    rank 1 opens them afterwards.  The capacity of an exchange goes by its index, so both ranks size exchanges 1 .. AHEAD
+    alike (the old capacity), and the grown one holds from the same exchange on both."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sdist.AsyncRecordGather(width=80, cap=64)
+        n_ex = 9
+        sizes = [(5000, 3)] + [(70 + k, 4000 if k == 3 else 10) for k in range(1, n_ex)]    # (rank 0, rank 1) per exchange
+        recs = [_recs([(0, 37 + rank, 100000 * k + i) for i in range(sizes[k][rank])]) for k in range(n_ex)]
+        outs, caps = [], []
+
+        def begin(k):
+            g.begin(len(recs[k])); caps.append(g.cur["cap"]); g.append(recs[k]); g.close()
+        # (launches and finishes come in the same order on both ranks, as they must: only WHEN an exchange is opened differs)
+        if rank == 0:       # opens 0, 1, 2 before anything is finished ...
+            begin(0); begin(1); begin(2)
+            g.launch()
+            outs.append(g.finish())         # ... exchange 0 overflowed: the capacity grows, in force from exchange 0 + AHEAD + 1
+            g.launch(); g.launch()
+            nxt = 3
+        else:               # ... rank 1 opens 1 and 2 only after it has finished 0
+            begin(0); g.launch()
+            outs.append(g.finish())
+            begin(1); begin(2); g.launch(); g.launch()
+            nxt = 3
+        for k in range(nxt, n_ex):
+            while len(g.inflight) >= 2:
+                outs.append(g.finish())
+            begin(k); g.launch()
+        while g.inflight:
+            outs.append(g.finish())
+        q.put((rank, caps, [None if o is None else len(o) for o in outs]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capacity_goes_by_the_exchange_index_gloo_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overflow_straddle, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (caps, outs)) for r, caps, outs in (q.get(timeout=180), q.get(timeout=180)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    caps0, outs0 = res[0]
+    caps1, outs1 = res[1]
+    assert caps0 == caps1                                   # every exchange has the same capacity on both ranks
+    A = sdist.AsyncRecordGather.AHEAD
+    assert caps0[:A + 1] == [64] * (A + 1) and caps0[A + 1] >= 5000 and caps0[-1] >= 5000
+    sizes = [(5000, 3)] + [(70 + k, 4000 if k == 3 else 10) for k in range(1, 9)]
+    assert outs0 == [a + b for a, b in sizes] and all(o is None for o in outs1)       # nothing lost in the overflowing ones
+
+
+def _worker_order(rank, world, port, q):
+    """Two gathers on one process group launched in different orders on the two ranks: their 32-byte header collectives
+    have equal sizes and would pair up crosswise without anyone noticing; the launch ticket in the header makes finish()
+    raise on every rank."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = sdist.AsyncRecordGather(width=80, cap=64)
+        b = sdist.AsyncRecordGather(width=80, cap=64)
+        r = _recs([(0, 37 + rank, i) for i in range(5)])
+        for g in (a, b):
+            g.begin(5); g.append(r); g.close()
+        order = (a, b) if rank == 0 else (b, a)
+        for g in order:
+            g.launch()
+        err = 0
+        for g in order:
+            try:
+                g.finish()
+            except RuntimeError as e:
+                err += "different orders" in str(e)
+        q.put((rank, err))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gathers_launched_in_different_orders_are_caught_gloo_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_order, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((q.get(timeout=180), q.get(timeout=180)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == 2 and res[1] == 2
 
 
 def test_device_dedup_equals_host_dedup():

@@ -126,13 +126,13 @@ def test_lane_shapes_match_oracle(oracle, core, warmup):
 
 
 def test_golden_zigbee_fixture_on_gpu():
-    """The committed 802.15.4 capture through the C ABI with default lane shape == committed records."""
+    """The committed 802.15.4 capture through the C ABI with the fixture's lane shape == committed records."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_oracle_zigbee import _golden_zigbee, _records_equal
     x, exp = _golden_zigbee()
-    with _rx(channel=exp["channel"]) as rx:
+    with _rx(channel=exp["channel"], zb_core=exp["core"], zb_warmup=exp["warmup"]) as rx:
         got = rx.process(x, first_sample_index=exp["first_sample_index"])
     _records_equal(got, exp)
 
