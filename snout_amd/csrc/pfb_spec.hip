@@ -396,15 +396,56 @@ void pfb_spec(const PfbMfArgs A)
             // OUT outputs from one window of OUT + 15 samples: the first four outputs need samples 0..18, every further
             // four outputs four more, read while the four before them are computed
             v2f wv[OUT + P - 1];
-#pragma unroll
-            for (int q = 0; q < 19; q++)
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(a0), "n"(q * M * 8) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
-                           "+v"(wv[7]), "+v"(wv[8]), "+v"(wv[9]), "+v"(wv[10]), "+v"(wv[11]), "+v"(wv[12]),
-                           "+v"(wv[13]), "+v"(wv[14])
-                         :: "memory");
-            asm volatile("" : "+v"(wv[15]), "+v"(wv[16]), "+v"(wv[17]), "+v"(wv[18]) :: "memory");
+            // the 19 reads and their wait as ONE statement (the values must not be touched between the two; the
+            // prefetches inside the loop below stay split from their waits on purpose -- they run under the FMAs -- and
+            // tests/test_asm_hazards.py checks the ISA for a use in between)
+            if constexpr (M == 40) {
+                asm volatile("ds_read_b64 %0, %19 offset:0\n\t"
+                             "ds_read_b64 %1, %19 offset:320\n\t"
+                             "ds_read_b64 %2, %19 offset:640\n\t"
+                             "ds_read_b64 %3, %19 offset:960\n\t"
+                             "ds_read_b64 %4, %19 offset:1280\n\t"
+                             "ds_read_b64 %5, %19 offset:1600\n\t"
+                             "ds_read_b64 %6, %19 offset:1920\n\t"
+                             "ds_read_b64 %7, %19 offset:2240\n\t"
+                             "ds_read_b64 %8, %19 offset:2560\n\t"
+                             "ds_read_b64 %9, %19 offset:2880\n\t"
+                             "ds_read_b64 %10, %19 offset:3200\n\t"
+                             "ds_read_b64 %11, %19 offset:3520\n\t"
+                             "ds_read_b64 %12, %19 offset:3840\n\t"
+                             "ds_read_b64 %13, %19 offset:4160\n\t"
+                             "ds_read_b64 %14, %19 offset:4480\n\t"
+                             "ds_read_b64 %15, %19 offset:4800\n\t"
+                             "ds_read_b64 %16, %19 offset:5120\n\t"
+                             "ds_read_b64 %17, %19 offset:5440\n\t"
+                             "ds_read_b64 %18, %19 offset:5760\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]), "=&v"(wv[4]), "=&v"(wv[5]), "=&v"(wv[6]), "=&v"(wv[7]), "=&v"(wv[8]), "=&v"(wv[9]), "=&v"(wv[10]), "=&v"(wv[11]), "=&v"(wv[12]), "=&v"(wv[13]), "=&v"(wv[14]), "=&v"(wv[15]), "=&v"(wv[16]), "=&v"(wv[17]), "=&v"(wv[18])
+                             : "v"(a0) : "memory");
+            } else {
+                asm volatile("ds_read_b64 %0, %19 offset:0\n\t"
+                             "ds_read_b64 %1, %19 offset:128\n\t"
+                             "ds_read_b64 %2, %19 offset:256\n\t"
+                             "ds_read_b64 %3, %19 offset:384\n\t"
+                             "ds_read_b64 %4, %19 offset:512\n\t"
+                             "ds_read_b64 %5, %19 offset:640\n\t"
+                             "ds_read_b64 %6, %19 offset:768\n\t"
+                             "ds_read_b64 %7, %19 offset:896\n\t"
+                             "ds_read_b64 %8, %19 offset:1024\n\t"
+                             "ds_read_b64 %9, %19 offset:1152\n\t"
+                             "ds_read_b64 %10, %19 offset:1280\n\t"
+                             "ds_read_b64 %11, %19 offset:1408\n\t"
+                             "ds_read_b64 %12, %19 offset:1536\n\t"
+                             "ds_read_b64 %13, %19 offset:1664\n\t"
+                             "ds_read_b64 %14, %19 offset:1792\n\t"
+                             "ds_read_b64 %15, %19 offset:1920\n\t"
+                             "ds_read_b64 %16, %19 offset:2048\n\t"
+                             "ds_read_b64 %17, %19 offset:2176\n\t"
+                             "ds_read_b64 %18, %19 offset:2304\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]), "=&v"(wv[4]), "=&v"(wv[5]), "=&v"(wv[6]), "=&v"(wv[7]), "=&v"(wv[8]), "=&v"(wv[9]), "=&v"(wv[10]), "=&v"(wv[11]), "=&v"(wv[12]), "=&v"(wv[13]), "=&v"(wv[14]), "=&v"(wv[15]), "=&v"(wv[16]), "=&v"(wv[17]), "=&v"(wv[18])
+                             : "v"(a0) : "memory");
+            }
 #pragma unroll
             for (int i0 = 0; i0 < OUT; i0 += 4) {
                 if (i0 < OUT - 4) {
