@@ -464,7 +464,7 @@ def read_peak(x, device):
 def traffic_from_profiles(workload: str, kernel: str, n: int):
     """PMC-derived HBM bytes per launch of the same kernel / workload, from the committed profile
     pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected); None when there is none."""
-    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -510,7 +510,7 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
     caps = []
     for sc, tile, n_rank, seed in ((sb, tb, nb_rank, 3), (sz, tz, nz_rank, 4)):
         n_total = n_rank * world
-        segs = sdist.shard_segments(n_total, sc.seg_len, sc.overlap, rank, world, sc.preroll)
+        segs = sdist.shard_segments(n_total, sc.seg_len, sc.overlap, rank, world, sc.preroll, uniform=True)
         n_local = len(segs) * sc.seg_len + sc.overlap + sc.preroll
         x = resident_capture(tile, n_local, seed=seed + 10 * rank, device=device, shift=sc.preroll)
         S, pre = sc.seg_len, sc.preroll
@@ -670,6 +670,8 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
                     parts = []
                     for j, (a, b) in enumerate(sc._segs):
                         host = src(a, b).cpu().numpy()
+                        if (b - a) < sc.pad_to:         # the capture's last segment, padded to the batch's length as the scan pads it
+                            host = np.concatenate([host, np.zeros(2 * (sc.pad_to - (b - a)), dtype=host.dtype)])
                         rec = oracle_py.wideband_segment(host, proto=sc.proto, first_sample_index=a // sc.decim)
                         own = (j * sc.seg_len) // sc.decim if (j and sc.preroll) else 0       # world 1: local segment j = global j
                         parts.append(rec[rec["sample_index"] >= own] if own else rec)

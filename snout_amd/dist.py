@@ -17,14 +17,15 @@ from ._ffi import PKT_DTYPE
 REC = PKT_DTYPE.itemsize  # 160
 
 
-def group_submissions(segs, batch: int):
+def group_submissions(segs, batch: int, pad_to: int = 0):
     """Runs of up to ``batch`` consecutive segments of EQUAL length: what one
     ``snout_rx_submit_batch_dev`` call may carry.  Returns lists of indices into ``segs``; a segment of
-    another length (the first one of a pre-rolled scan, the last one of a capture) starts a new run."""
+    another length starts a new run.  ``pad_to``: a shorter segment counts as that long (the caller pads it with zeros)."""
     batch = max(1, int(batch))
     runs = []
+    length = lambda j: max(segs[j][1] - segs[j][0], pad_to)
     for j, (a, b) in enumerate(segs):
-        if runs and len(runs[-1]) < batch and (b - a) == (segs[runs[-1][0]][1] - segs[runs[-1][0]][0]):
+        if runs and len(runs[-1]) < batch and length(j) == length(runs[-1][0]):
             runs[-1].append(j)
         else:
             runs.append([j])
@@ -32,19 +33,20 @@ def group_submissions(segs, batch: int):
 
 
 def shard_segments(n_total: int, seg_len: int, overlap: int, rank: int, world: int,
-                   preroll: int = 0) -> List[Tuple[int, int]]:
+                   preroll: int = 0, uniform: bool = False) -> List[Tuple[int, int]]:
     """Cut [0, n_total) into segments of seg_len samples that each extend `overlap` samples into
     the next one (so a packet straddling a cut is whole in the earlier segment), and deal them
     round-robin: segment i -> rank i % world.  Returns this rank's [(start, stop), ...].
     ``preroll`` > 0 lets every segment but the first start that many samples early (a receiver
     with a start-up transient settles there; its records from before i * seg_len are the previous
-    segment's to report)."""
+    segment's to report).  ``uniform``: the first segment, which has nothing to pre-roll over, reads ``preroll`` samples
+    more at its end instead, so that every segment that does not touch the capture's end has the same length (one batch)."""
     assert seg_len > 0 and overlap >= 0 and preroll >= 0 and 0 <= rank < world
     out = []
     i = 0
     start = 0
     while start < n_total:
-        stop = min(start + seg_len + overlap, n_total)
+        stop = min(start + seg_len + overlap + (preroll if (uniform and i == 0) else 0), n_total)
         if i % world == rank:
             out.append((max(0, start - preroll), stop))
         start += seg_len

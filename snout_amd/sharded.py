@@ -47,6 +47,13 @@ class ShardedScan:
         pre = 0 if proto == PROTO_BTLE else ZIGBEE_PREROLL_CH * self.decim
         self.preroll = (pre + step - 1) // step * step                # in input samples
         self.batch = max(1, int(batch))
+        # Batched scans: every segment of a submission has to be equally long.  The first segment reads its pre-roll's
+        # worth at its end instead (dist.shard_segments(uniform=True)), and a segment that the capture's end cuts short is
+        # padded with zeros to the common length (it decodes nothing there): a capture's segments then go to the library as
+        # ONE submission instead of three -- each submission costs a lane's whole serial clock recovery however few
+        # samples it holds (cfg #5: three 802.15.4 submissions per step cost 3 x ~1.2 ms of zb_mm, profiles/r5_cfg5.md)
+        # (done for every batch size, 1 included, so that what a capture decodes to does not depend on the batch)
+        self.pad_to = self.seg_len + self.overlap + self.preroll
         self.stream_priority = int(stream_priority)                   # of the handles' streams (-1: high: the scan's small kernels go first)
         self.depth = max(1, min(3, int(depth)))                       # submissions in flight per handle (the library holds 3)
         if self.batch > 1:
@@ -61,11 +68,17 @@ class ShardedScan:
         for rx in self.rxs:
             rx.close()
 
+    @staticmethod
+    def zero_pad(x, n_more: int):
+        """``x`` (a device tensor of interleaved samples, any format) followed by ``n_more`` complex samples of zeros."""
+        import torch
+        return torch.cat([x.reshape(-1), torch.zeros(2 * n_more, dtype=x.dtype, device=x.device)])
+
     def my_segments(self, n_total: int, group=None):
         import torch.distributed as tdist
         world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         rank = tdist.get_rank(group) if tdist.is_initialized() else 0
-        return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world, self.preroll)
+        return sdist.shard_segments(n_total, self.seg_len, self.overlap, rank, world, self.preroll, uniform=True)
 
     # ---- a scan as a sequence of steps, so that several scans can share a GPU (run_concurrent)
     def start(self, n_total: int, source: Callable[[int, int], "object"], group=None, sink=None,
@@ -102,7 +115,7 @@ class ShardedScan:
         if not self.active():
             self._parts = []
         # submissions: runs of up to `batch` consecutive segments of equal length
-        subs = sdist.group_submissions(self._segs, self.batch)
+        subs = sdist.group_submissions(self._segs, self.batch, self.pad_to)
         for k, sub in enumerate(subs):
             self._jobs.append(dict(segs=[self._segs[i] for i in sub], own=[own_from[i] for i in sub], source=source, sink=sink,
                                    on_first=on_first if k == 0 else None, on_last=on_last if k == len(subs) - 1 else None))
@@ -145,6 +158,8 @@ class ShardedScan:
                 self._appended[j % H] = None
             with torch.cuda.stream(st):
                 xs = [job["source"](a, b) for a, b in job["segs"]]
+                if self.pad_to:
+                    xs = [x if (b - a) >= self.pad_to else self.zero_pad(x, self.pad_to - (b - a)) for x, (a, b) in zip(xs, job["segs"])]
                 if self.batch > 1:
                     # the library drops what a segment finds before its own range (its pre-roll)
                     self.rxs[j % H].submit_batch(xs, [a // self.decim for a, _ in job["segs"]],
