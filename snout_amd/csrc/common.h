@@ -186,6 +186,8 @@ struct PfbCtx {
                                      // leave room for other streams' kernels; pfb_spec.hip's one 16-wave workgroup per CU does not)
     int impl = 4;                    // SNOUT_PFB_IMPL, M = 40 kernel: 0 valu = pfb.hip, 1 mfma / 2 spec16 = pfb_mfma.hip with its FIR on the matrix / vector pipe, 3 spec12 / 4 spec = pfb_spec.hip with 12 / 16 waves
     DevBuf d_proto, d_tw, d_tw5, d_y;
+    bool gate = false;               // SNOUT_PFB_GATE=1 (A/B): every handle's channelizer launches go through one shared stream
+    hipEvent_t ev_gate_in = nullptr, ev_gate_out = nullptr;
     uint32_t min_item_tiles = 48;    // SNOUT_PFB_MIN_ITEM: fewest tiles of one workgroup's range when a batch is cut finer than one range per CU
     int init(uint32_t M, uint32_t n_cus = 256, uint32_t reserved_cus = 0);
     void destroy();
@@ -232,6 +234,7 @@ struct ZbCtx {
     // d_iq == nullptr: the fused channelizer has already written d and S (see pfb_target)
     int enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
                       bool time_front, int fmt = 0);
+    int enqueue_lanes(uint64_t n_channel_samples, hipStream_t st);     // IIR carry-in + zb_mm (behind enqueue_front's part)
     PfbZbTarget pfb_target(uint32_t seg = 0) const;
     unsigned long long* seam_masks() const;         // per lane: XOR of the two timing loops' last 48 chips before its seam
     int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s, bool time_front);

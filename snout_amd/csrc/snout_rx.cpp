@@ -212,8 +212,12 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         ZbCtx& z = zb_of(h, s);
         if (int rc = z.reserve(n_ch, s.segs.count)) return rc;
         if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
+        // the lanes: a narrowband handle's on the work set's stream (the next segment's discriminator overlaps them),
+        // a wideband handle's behind its channelizer (see ZbCtx::enqueue_lanes)
+        if (h->wide) { if (int rc = z.enqueue_lanes(n_ch, st)) return rc; }
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
+        if (!h->wide) { if (int rc = z.enqueue_lanes(n_ch, tail)) return rc; }
         if (int rc = z.enqueue_tail(n_ch, s.segs, tail, s, !h->wide)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));

@@ -239,20 +239,22 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     uint64_t hist = 0, hist_cand = 0;
     const bool tap = TAP && active && g == soft_lane && soft_chips != nullptr;
     float* zcol = &zb[l];                                   // sample j of this lane at zcol[64 j]
-    float zl[8];
+    // the 8 samples of history in front of a half are the last 8 rows of the half before it: copied inside LDS (this
+    // lane's own column; a wave's LDS operations execute in order) instead of kept in 8 registers
 #pragma unroll
-    for (int k = 0; k < 8; k++) zl[k] = 0.0f;
+    for (int k = 0; k < 8; k++) zcol[64 * (32 + k)] = 0.0f;
 
     // The lane's samples are a row of d: tile t = 64 floats at d_row + 64 t, fetched as 16-byte
     // pieces one tile ahead.  Every lane reads its own row (the 64 lanes of a load touch 64 lines,
     // each line is used by eight consecutive loads) -- the texture path has room for that beside
     // ~2 600 VALU instructions per tile, and nothing has to be transposed anywhere.
     const float* d_row = d + (uint64_t)(active ? g / lanes_per_slot : 0u) * d_stride + (active ? s0 : 0ull);
-    float pre[64];
+    // (half a tile in registers, the next half in flight during the half's M&M steps: 32 registers instead of 64)
+    float pre[32];
     {
         const float4* tp = reinterpret_cast<const float4*>(d_row);
 #pragma unroll
-        for (uint32_t c4 = 0; c4 < 16u; c4++) {
+        for (uint32_t c4 = 0; c4 < 8u; c4++) {
             const float4 v4 = tp[c4];
             pre[4 * c4] = v4.x; pre[4 * c4 + 1] = v4.y; pre[4 * c4 + 2] = v4.z; pre[4 * c4 + 3] = v4.w;
         }
@@ -275,27 +277,26 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
         for (uint32_t hb = 0; hb < 64u; hb += 32u) {
             if (hb < nz) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) zcol[64 * k] = zl[k];
+                for (int k = 0; k < 8; k++) zcol[64 * k] = zcol[64 * (32 + k)];
 #pragma unroll
                 for (uint32_t q = 0; q < 32u; q += 8u) {
                     if (hb + q < nz) {
 #pragma unroll
                         for (uint32_t k = 0; k < 8u; k++) {
-                            const float x = pre[hb + q + k];
+                            const float x = pre[q + k];
                             lp = alpha * (double)x + one_minus * lp;
                             const float z = x - (float)lp;
                             zcol[64u * (8u + q + k)] = z;
-                            zl[k] = z;
                             if constexpr (TAP) { if (tap && soft_z && r0 + hb + q + k < soft_cap) soft_z[r0 + hb + q + k] = z; }
                         }
                     }
                 }
             }
-            // next tile's samples: in flight during the second half's M&M steps
-            if (hb == 32u && tile + 1u < nt) {
-                const float4* tp = reinterpret_cast<const float4*>(d_row + 64u * (tile + 1u));
+            // the next half's samples: in flight during this half's M&M steps
+            if (hb == 0u || tile + 1u < nt) {
+                const float4* tp = reinterpret_cast<const float4*>(d_row + 64u * tile + hb + 32u);
 #pragma unroll
-                for (uint32_t c4 = 0; c4 < 16u; c4++) {
+                for (uint32_t c4 = 0; c4 < 8u; c4++) {
                     const float4 v4 = tp[c4];
                     pre[4 * c4] = v4.x; pre[4 * c4 + 1] = v4.y; pre[4 * c4 + 2] = v4.z; pre[4 * c4 + 3] = v4.w;
                 }
@@ -1676,7 +1677,8 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     return SNOUT_EINVAL;
 }
 
-// Front end (a4-a6) on the caller's stream: discriminator tiles, IIR carry-in, lanes.
+// Front end, first part (a4) on the caller's stream: the discriminator rows and the IIR sub-block sums of a narrowband
+// segment (a wideband handle's fused channelizer has written them already: d_iq == nullptr).
 // iq: [n_slots][iq_stride] complex samples at 4 Msps per channel, device memory.  No host sync.
 int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
                          ResultSlot& s, bool time_front, int fmt)
@@ -1693,6 +1695,19 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
         else SNOUT_ZBD(kFmtCf32);
 #undef SNOUT_ZBD
     }
+    SNOUT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Front end, second part (a5-a6): IIR carry-in and the lanes.  A narrowband handle runs them on the work set's own (tail)
+// stream, so that the NEXT segment's discriminator (a streaming kernel: HBM-bound, 44 registers) runs beside them; a
+// wideband handle keeps them on the caller's stream behind the channelizer -- beside the next channelizer they were
+// measured too (zb_mm cut to 96 registers so that it fits next to the channelizer's four waves per SIMD): the
+// channelizer's 16 fast_atan2f per output time keep the vector pipe as busy as the lanes need it, it took 3.5 ms instead
+// of 1.8 and the step did not move (profiles/r5_repair.md).  No host sync.
+int ZbCtx::enqueue_lanes(uint64_t n, hipStream_t st)
+{
+    if (n < 9u) return 0;
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
     hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),

@@ -1,4 +1,4 @@
-"""Dev tool: kernel timeline of the last steps from a rocprofv3 sqlite database.  python tools/r5_tl.py x_results.db [steps]"""
+"""Dev tool: kernel timeline of the last timed steps from a rocprofv3 sqlite database.  python tools/r5_tl.py x_results.db [steps [skip]]"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -6,7 +6,8 @@ kd = [t for t in tabs if 'kernel_dispatch' in t][0]; sym = [t for t in tabs if '
 rows = list(cur.execute(f"select s.kernel_name, d.start, d.end, d.queue_id from {kd} d join {sym} s on d.kernel_id=s.id order by d.start"))
 idx = [i for i, r in enumerate(rows) if 'pfb_spec' in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-i0 = idx[-(k + 3)]; i1 = idx[-3]; t0 = rows[i0][1]
+off = int(sys.argv[3]) if len(sys.argv) > 3 else 8          # channelizer launches behind the timed steps (checks, one-lane runs)
+i0 = idx[-(k + off)]; i1 = idx[-off]; t0 = rows[i0][1]
 for r in rows[i0:i1 + 1]:
     nm = r[0].replace('_ZN5snout', '')[:14]
     if (r[2] - r[1]) < 30000: continue
