@@ -625,11 +625,18 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
                  * loop is asked -- the one sequential loop's may differ too.  A repaired frame (SNOUT_PKT_ZB_REPAIRED)
                  * has no seams. */
                 if (fin == &rs) p->flags |= 8u;
-                else for (uint64_t m = 1; m < n_lanes; m++) {
-                    if (o[m] <= s.trigger || o[m] > q) continue;
-                    const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
-                    const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
-                    if (seam[m] & mask) p->flags |= 4u;
+                else {
+                    /* the seams o[m] in (trigger, q]: o[] ascends and the SFD chip is lane l's, so they are lanes
+                     * l, l - 1, ... while o[m] > trigger and l + 1, l + 2, ... while o[m] <= q */
+                    uint64_t m0 = l;
+                    while (m0 > 1 && o[m0 - 1] > s.trigger) m0--;
+                    if (m0 < 1) m0 = 1;
+                    for (uint64_t m = m0; m < n_lanes && o[m] <= q; m++) {
+                        if (o[m] <= s.trigger) continue;
+                        const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
+                        const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
+                        if (seam[m] & mask) p->flags |= 4u;
+                    }
                 }
                 memcpy(p->bytes, fin->pkt, (size_t)fin->packetlen_cnt);
                 p->crc_ok = (uint8_t)crc_ok;
