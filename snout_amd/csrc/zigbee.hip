@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     s.lqi = s.lqi_cnt = 0; s.trigger = 0; s.c0 = s.c1 = s.c2 = 0; s.b_prev = s.b_last = 0;
     uint32_t n_pk = 0, sync_q = 0;
     bool snapped = false;           // this sink was busy with a synchronised frame at its lane's seam (snaps[g] holds it there)
-    const bool has_next = li + 1u < lanes_per_slot;
+    const bool has_next = li + 1u < lanes_per_slot && snaps != nullptr;      // (snaps == nullptr: the repair is switched off)
     uint32_t q = own0 > kSinkWarmChips ? own0 - kSinkWarmChips : 0u;
     ChipReader rd;
     rd.open(sw, q);
@@ -1619,7 +1619,7 @@ int ZbCtx::launch_sinks(uint64_t n, const SegBatch& segs, hipStream_t st)
                        stream_words, offs, first_owned, slot_total,
                        d_TR.as<uint32_t>(), nt, lanes_per_slot, total_lanes, core, warmup, threshold,
                        d_slot_channel.as<uint16_t>(), segs, d_stage.as<snout_pkt>(), pkts_per_lane,
-                       d_lane_cnt.as<uint32_t>(), d_snap.as<ZbSnap>(), d_req.as<uint32_t>(), tail_prio & 1u);
+                       d_lane_cnt.as<uint32_t>(), repair ? d_snap.as<ZbSnap>() : nullptr, d_req.as<uint32_t>(), tail_prio & 1u);
     // frame repair: at most one request per lane; the waves beyond the count return at once
     if (repair)
         hipLaunchKernelGGL(zb_repair, dim3(cdiv(total_lanes, 64)), dim3(64), 0, st, d_d.as<float>(), d_stride, n, lanes_per_slot,
