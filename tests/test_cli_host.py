@@ -106,3 +106,19 @@ def test_btle_scan_stop_rules_without_gpu(monkeypatch):
     monkeypatch.setattr(scan2, "lines", lambda ch: ((setattr(scan2, "_elapsed", i * 0.1), line)[1]
                                                      for i in range(10)))
     assert len(scan2.run()) == 3                # stops once capture time >= timeout
+
+
+def test_wideband_scans_refuse_live_streams(tmp_path):
+    """`--iq -` / a FIFO is a live stream, implemented for the single-channel scans; with --wideband / --sharded the
+    value used to reach WidebandSource, which opened a file literally named '-'.  Now a usage error, before anything touches
+    the GPU."""
+    import os
+    from click.testing import CliRunner
+    from snout_amd import cli
+    fifo = str(tmp_path / "iq.fifo")
+    os.mkfifo(fifo)
+    for proto in ("btle", "zigbee"):
+        for how in ("--wideband", "--sharded"):
+            for iq in ("-", fifo):
+                r = CliRunner().invoke(cli.main, [proto, "scan", how, "--iq", iq, "-c", "all", "-t", "1"])
+                assert r.exit_code == 2 and "capture FILE" in r.output, (proto, how, iq, r.output)

@@ -133,3 +133,34 @@ def test_downloads_sized_by_the_exchange_before_still_deliver_everything(tol):
         o = sdist.widen_records(o)
         first = o[o["sample_index"] < (1 << 40)]
         assert first.tobytes() == recs[:n].tobytes()
+
+
+def test_a_capture_without_segments_for_this_rank_takes_its_turn():
+    """a rank that has no segment of a capture used to call on_first / on_last immediately inside start(), i.e. while
+    the exchange of the capture BEFORE was still being filled (AsyncRecordGather.begin() then asserts).  The callbacks now ride
+    on an empty job and fire in the collection order.  And a scan that keeps its records on the device refuses to be collected
+    to the host."""
+    import torch
+    from snout_amd import synth
+    from snout_amd.sharded import ShardedScan
+    x, _ = synth.wideband_capture(0, 40 * (1 << 16), seed=5, sigma=0.02)
+    cap = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    n_in = cap.numel() // 2
+    src = lambda a, b: cap[2 * a:2 * b]
+    sc = ShardedScan(0, n_channels=40, seg_len=40 * (1 << 14), batch=2)
+    events = []
+    sc.start(n_in, src, on_first=lambda: events.append("A first"), on_last=lambda: events.append("A last"))
+    mine = sc.my_segments
+    sc.my_segments = lambda n_total, group=None: []          # the next capture has nothing for this rank
+    sc.start(n_in, src, on_first=lambda: events.append("B first"), on_last=lambda: events.append("B last"))
+    sc.my_segments = mine
+    sc.start(n_in, src, on_first=lambda: events.append("C first"), on_last=lambda: events.append("C last"))
+    assert events == []                                      # nothing fires inside start()
+    while sc.active():
+        sc.step()
+    assert events == ["A first", "A last", "B first", "B last", "C first", "C last"]
+    sc.close()
+    dev = ShardedScan(0, n_channels=40, seg_len=40 * (1 << 14), batch=2, records_on_device=True)
+    with pytest.raises(RuntimeError, match="records on the device"):
+        dev.run(n_in, src)
+    dev.close()
