@@ -298,7 +298,7 @@ def reserved_cus(world: int, fake: int) -> int:
 # one workload on one handle, pipelined submit / collect
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, world: int, fmt: int = 0,
-                 sync: bool = False, gather=None, keep_capture: bool = False, parity_samples: int = 0):
+                 sync: bool = False, gather=None, keep_capture: bool = False, parity_samples: int = 0, checks: bool = True):
     import torch
     import torch.distributed as dist
     from snout_amd.rx import SnoutRx
@@ -438,7 +438,7 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
         # the whole capture where the oracle finishes it in seconds (first_sample_index 0: rank 0's own capture)
         full = parity_samples >= n and rank == 0
         res["parity_in_run"] = parity_in_run(x, name, min(parity_samples, n), device, fmt, got=local if full else None)
-    if proto == 1 and rank == 0 and not os.environ.get("SNOUT_BENCH_ZB_CORE"):
+    if checks and proto == 1 and rank == 0 and not os.environ.get("SNOUT_BENCH_ZB_CORE"):
         # what the default (timed) decode loses against the reference's one sequential loop
         res["frames_lost_vs_sequential"] = lost_vs_sequential(x, name, min(n, (1 << 25) if n_ch > 1 else (1 << 24)), device, fmt)
     if keep_capture:
@@ -831,7 +831,7 @@ def main():
         gather = (sdist.AsyncRecordGather(device, width=WORKLOADS[headline][4], fake_world=fake)
                   if (world > 1 or dist.is_initialized() or fake > 1) else None)
         res, x = run_workload(headline, n, args.steps, args.warmup, device, rank, world, fmt=fmt, sync=args.sync,
-                              gather=gather, keep_capture=True)
+                              gather=gather, keep_capture=True, checks=not args.no_cpu)       # (--no-cpu: profiling runs, no checks)
         if rank == 0:
             traffic, tsrc = (traffic_from_profiles(headline, res["kernel"], n) if fmt == 0 else (None, None))
             rbest, rmean = read_peak(x, device)
@@ -877,7 +877,7 @@ def main():
             k = max(3, min(args.steps, 10))
             for name in ("cfg2", "cfg4", "zigbee1"):
                 nn = int(WORKLOADS[name][3])
-                r, _ = run_workload(name, nn, k, 1, device, 0, 1,
+                r, _ = run_workload(name, nn, k, 1, device, 0, 1, checks=not args.no_cpu,
                                     parity_samples=0 if args.no_cpu else (nn if (name in PARITY_FULL and args.parity != "prefix")
                                                                           else int(CPU_SAMPLES[name]) // 4))
                 others[name] = {f: r[f] for f in r if f in ("workload", "value", "unit", "ms_per_step", "steps", "kernel",

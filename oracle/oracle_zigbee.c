@@ -449,8 +449,6 @@ double* oracle_zb_iir_carry(const float* d, uint64_t n, uint32_t core, uint32_t 
 /* Developer aid (tools/ only): when set, channel_lanes copies its stitched chip stream, the chips' window starts and the
  * lanes' first owned chips here. */
 uint8_t* g_dbg_bits = NULL; uint64_t* g_dbg_pos = NULL; uint64_t* g_dbg_first = NULL; uint64_t g_dbg_cap = 0, g_dbg_n = 0, g_dbg_lanes = 0;
-/* Developer aid: counters of the last channel_lanes calls (requests, repaired, given up again); not thread-safe sums are fine for a tool */
-uint64_t g_dbg_repair[4] = {0, 0, 0, 0};
 
 /* Frame repair: lane l's loop (state `m` at its core end) and its sink (state `s` at the seam, stream chip q0) go on with
  * the frame the sink is busy with -- over the next lane's samples; where the lane after that takes over (hand_pos = window
@@ -556,8 +554,13 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
         g_dbg_lanes = n_lanes;
         if (g_dbg_first) memcpy(g_dbg_first, o, (n_lanes + 1) * 8);
     }
-    uint64_t busy_end = 0;          /* last chip of the frame kept last (sequential rule) */
-    int have_kept = 0;
+    /* The sinks of the lanes are independent (each reads the stitched stream; a frame repair reads the samples): they run
+     * over the OpenMP threads when more than one is set and leave their candidate frames, in order, per lane; the
+     * sequential rule (Resolve) then passes over the candidates in lane order. */
+    typedef struct { uint64_t trigger, end_chip; snout_pkt pkt; } cand_t;
+    cand_t** cands = (cand_t**)calloc(n_lanes ? n_lanes : 1, sizeof(cand_t*));
+    uint32_t* ncand = (uint32_t*)calloc(n_lanes ? n_lanes : 1, sizeof(uint32_t));
+#pragma omp parallel for schedule(dynamic, 16)
     for (uint64_t l = 0; l < n_lanes; l++) {
         lane_t s;
         memset(&s, 0, sizeof(s));
@@ -585,14 +588,12 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
                 crc_ok = ((c & 0xFF) == s.pkt[s.packetlen_cnt - 2]) && ((c >> 8) == s.pkt[s.packetlen_cnt - 1]);
             }
             if (g_zb_repair && have_snap && q >= o[l + 1] && (gave_up || !crc_ok || g_zb_repair == 2)) {
-                g_dbg_repair[0]++;
                 rs = snap;
                 uint64_t rend = 0;
                 /* lane l + 2 takes over again if it owns chips (hand_q > 0 then: it is not the channel's first lane) */
                 const int hb = l + 2 < n_lanes && o[l + 2] < o[l + 3] && core <= (1u << 23);     /* (lane-relative keys in 32 bits) */
                 const int ok = repair_frame(d, n, ends[l], o[l + 1], threshold, &rs, hb ? spos[o[l + 2]] : 0u, hb ? o[l + 2] : 0u,
                                             sb, total, &rend);
-                g_dbg_repair[ok ? 1 : 2]++;
                 if (!ok) { if (done) enter_search(&s); continue; }
                 fin = &rs;
                 end_chip = rend;
@@ -604,47 +605,60 @@ static void channel_lanes(const float* d, uint64_t n, uint64_t first_index, uint
             } else if (gave_up) {
                 continue;
             }
-            /* resolve: the sequential sink is busy until the end of the frame it kept last */
-            if (have_kept && s.trigger <= busy_end) { if (done) enter_search(&s); continue; }
-            have_kept = 1;
-            busy_end = end_chip;
-            if (*n_out < cap) {
-                snout_pkt* p = &out[*n_out];
-                memset(p, 0, sizeof(*p));
-                p->sample_index = first_index + idx;
-                p->proto = 1;
-                p->channel = (uint16_t)channel;
-                p->len = (uint16_t)fin->packetlen_cnt;
-                unsigned scaled = (fin->lqi / 8) << 3;
-                p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
-                p->aux = (uint32_t)l;
-                /* SNOUT_PKT_ZB_SEAM_DISAGREED.  Seams inside the frame = hand-overs from one lane's timing loop to
-                 * the next between the trigger chip and the last chip.  The two loops ran side by side over the 48
-                 * chips before the seam (seam[m]: XOR of their decisions, bit 0 = the last chip before it); if they
-                 * decided any of those that belong to the frame differently, the frame's chips depend on which
-                 * loop is asked -- the one sequential loop's may differ too.  A repaired frame (SNOUT_PKT_ZB_REPAIRED)
-                 * has no seams. */
-                if (fin == &rs) p->flags |= 8u;
-                else {
-                    /* the seams o[m] in (trigger, q]: o[] ascends and the SFD chip is lane l's, so they are lanes
-                     * l, l - 1, ... while o[m] > trigger and l + 1, l + 2, ... while o[m] <= q */
-                    uint64_t m0 = l;
-                    while (m0 > 1 && o[m0 - 1] > s.trigger) m0--;
-                    if (m0 < 1) m0 = 1;
-                    for (uint64_t m = m0; m < n_lanes && o[m] <= q; m++) {
-                        if (o[m] <= s.trigger) continue;
-                        const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
-                        const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
-                        if (seam[m] & mask) p->flags |= 4u;
-                    }
+            if ((ncand[l] & (ncand[l] - 1u)) == 0u)        /* grow at 0, 1, 2, 4, 8 ... */
+                cands[l] = (cand_t*)realloc(cands[l], (size_t)(ncand[l] ? 2u * ncand[l] : 1u) * sizeof(cand_t));
+            cand_t* cd = &cands[l][ncand[l]++];
+            cd->trigger = s.trigger;
+            cd->end_chip = end_chip;
+            snout_pkt* p = &cd->pkt;
+            memset(p, 0, sizeof(*p));
+            p->sample_index = first_index + idx;
+            p->proto = 1;
+            p->channel = (uint16_t)channel;
+            p->len = (uint16_t)fin->packetlen_cnt;
+            unsigned scaled = (fin->lqi / 8) << 3;
+            p->lqi = (uint8_t)(scaled >= 256 ? 255 : scaled);
+            p->aux = (uint32_t)l;
+            /* SNOUT_PKT_ZB_SEAM_DISAGREED.  Seams inside the frame = hand-overs from one lane's timing loop to
+             * the next between the trigger chip and the last chip.  The two loops ran side by side over the 48
+             * chips before the seam (seam[m]: XOR of their decisions, bit 0 = the last chip before it); if they
+             * decided any of those that belong to the frame differently, the frame's chips depend on which
+             * loop is asked -- the one sequential loop's may differ too.  A repaired frame (SNOUT_PKT_ZB_REPAIRED)
+             * has no seams. */
+            if (fin == &rs) p->flags |= 8u;
+            else {
+                /* the seams o[m] in (trigger, q]: o[] ascends and the SFD chip is lane l's, so they are lanes
+                 * l, l - 1, ... while o[m] > trigger and l + 1, l + 2, ... while o[m] <= q */
+                uint64_t m0 = l;
+                while (m0 > 1 && o[m0 - 1] > s.trigger) m0--;
+                if (m0 < 1) m0 = 1;
+                for (uint64_t m = m0; m < n_lanes && o[m] <= q; m++) {
+                    if (o[m] <= s.trigger) continue;
+                    const uint64_t inside = o[m] - s.trigger;       /* compared chips at or after the trigger */
+                    const uint64_t mask = inside >= 48 ? 0xFFFFFFFFFFFFull : ((1ull << inside) - 1ull);
+                    if (seam[m] & mask) p->flags |= 4u;
                 }
-                memcpy(p->bytes, fin->pkt, (size_t)fin->packetlen_cnt);
-                p->crc_ok = (uint8_t)crc_ok;
             }
-            (*n_out)++;
+            memcpy(p->bytes, fin->pkt, (size_t)fin->packetlen_cnt);
+            p->crc_ok = (uint8_t)crc_ok;
             if (done) enter_search(&s);
         }
     }
+    /* resolve: the sequential sink is busy until the end of the frame it kept last */
+    uint64_t busy_end = 0;          /* last chip of the frame kept last (sequential rule) */
+    int have_kept = 0;
+    for (uint64_t l = 0; l < n_lanes; l++) {
+        for (uint32_t k = 0; k < ncand[l]; k++) {
+            const cand_t* cd = &cands[l][k];
+            if (have_kept && cd->trigger <= busy_end) continue;
+            have_kept = 1;
+            busy_end = cd->end_chip;
+            if (*n_out < cap) out[*n_out] = cd->pkt;
+            (*n_out)++;
+        }
+        free(cands[l]);
+    }
+    free(cands); free(ncand);
     free(ends); free(seam); free(o); free(spos); free(sb); free(NC); free(LKEY); free(LPOS); free(LB); free(lp_in);
 }
 
