@@ -103,6 +103,7 @@ struct snout_rx {
     BtleCtx btle, btle2, btle3;
     ZbCtx zb2, zb3;           // (second and third Zigbee work set; the first is `zb`)
     hipStream_t tail_streams[3] = {nullptr, nullptr, nullptr};
+    bool one_tail = false;    // SNOUT_ONE_TAIL=1 (A/B): every work set's tail on one stream, as in rounds 1-4
     bool sync_call = false;   // inside snout_rx_process*: nothing to overlap, the tail stays on the caller's stream
     ZbCtx zb;
     PfbCtx pfb;
@@ -155,7 +156,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // -> 9.9 ms); behind a 1e9-sample front end the separate stream is worth 5 %.
     const uint64_t ch_samples = (h->wide ? h->pfb.n_out_for(s.n_in) * h->cfg.n_channels : s.n_in) * s.segs.count;
     const bool inline_tail = h->sync_call || (h->cfg.proto == SNOUT_PROTO_BTLE && ch_samples < (1ull << 26));
-    hipStream_t tail = inline_tail ? st : h->tail_streams[s.work_set];
+    hipStream_t tail = inline_tail ? st : h->tail_streams[h->one_tail ? 0 : s.work_set];
     // (the first kernel's start event ev_k0 also marks the start of the segment: every event on the
     //  caller's stream is a barrier packet, so there is no separate one)
     // the tail that last used this work set must be done; usually it is, and a wait that is not
@@ -382,6 +383,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
                        "Zigbee: 1 or 16)", c.proto, c.n_channels);
         goto fail;
     }
+    if (const char* e = getenv("SNOUT_ONE_TAIL")) h->one_tail = atoi(e) != 0;
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
     for (int k = 0; k < 3; k++) {
         if (hipEventCreate(&h->ws_free[k]) != hipSuccess) { rc = SNOUT_EHIP; goto fail; }
