@@ -857,6 +857,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         st_sym += __popcll(__ballot(alive && !(s.state == 0 && s.preamble_cnt == 0)));
 #endif
         bool fin = false, stepped = false, gave_up = false;
+        // Frame repair: a sink that is busy with a synchronised frame where its lane's chips end leaves a snapshot of itself
+        // there (at the symbol boundary at or before the seam).  A cooperative round below stops at the seam, which may be
+        // exactly a byte boundary: then the crossing is seen HERE, at the top of the next iteration (found by
+        // tools/fuzz_parity.py: the one-symbol path alone missed it and the frame was never asked for); otherwise in the
+        // one-symbol path, inside the symbol that straddles the seam.
+        if (has_next && !snapped && alive && s.state != 0 && q == own1) {
+            snapped = true;
+            ZbSnap sn;
+            sn.s = s; sn.q_b = q; sn.own1 = own1; sn.slot = n_pk; sn.pad = 0u;
+            snaps[g] = sn;
+        }
         // ---- payload, cooperatively.  A lane inside the payload of a frame (state 2, at a byte
         //      boundary, at least two bytes to go) would otherwise take one symbol per iteration while
         //      the other 63 lanes of the wave wait: instead the whole wave decodes up to 64 symbols of
