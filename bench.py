@@ -572,10 +572,14 @@ def run_cfg5(steps: int, warmup: int, device, rank: int, world: int, seconds: fl
 
     def run_steps(k):
         base = launched[0]
+        ahead = int(os.environ.get("SNOUT_CFG5_AHEAD", "2"))
         for i in range(k):
             queue_step()                            # step i's submissions are queued behind step i - 1's: no drain between
-            if i >= 1:
-                launch_next()                       # step i - 1 complete on both scans -> its exchanges
+            if i >= ahead:
+                # step i - ahead complete on both scans -> its exchanges.  Two steps stay queued behind the one being
+                # finished (round 5): with one, the scan that finishes its step first (BTLE) had nothing queued while the host
+                # waited for the other's (802.15.4: clock recovery + sinks + frame repair) -- 2-3 ms of idle channelizer per step
+                launch_next()
         while launched[0] < base + k:
             launch_next()
         while gb.inflight:                          # every step's records are on rank 0, de-duplicated
