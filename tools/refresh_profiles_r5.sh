@@ -18,7 +18,7 @@ for w in cfg2 cfg4 zigbee1; do
   timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${w}_write -- $B --workload $w --steps 2 --warmup 1 --no-cpu --sync > $O/${w}_write.log 2>&1
 done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- $B --workload cfg5 --steps 8 --warmup 3 > $O/cfg5.log 2>&1
-python3 $R/tools/timeline.py $O/cfg5 --marker "pfb_spec<40" --last 8 --per 1 --list 9 > $O/cfg5_timeline.txt 2>&1
+python3 $R/tools/timeline.py $O/cfg5 --marker "pfb_spec<40" --last 6 --per 1 --list 9 > $O/cfg5_timeline.txt 2>&1
 # cfg #4 pipelined (the frame repair and zb_walk beside the next segment's channelizer)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4_pipe -- $B --workload cfg4 --steps 10 --no-cpu > $O/cfg4_pipe.log 2>&1
 python3 $R/tools/timeline.py $O/cfg4_pipe --marker "pfb_spec<16" --last 6 --per 1 --list 12 > $O/cfg4_timeline.txt 2>&1
