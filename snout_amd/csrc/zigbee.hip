@@ -351,7 +351,66 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
                     nc++;
             }
             };
-            if (tile == tb) mm_steps(std::true_type{}); else mm_steps(std::false_type{});
+            // The same steps with fewer instructions (the loop is issue-bound as soon as a SIMD holds two of these waves,
+            // profiles/r5_repair.md section 6), for every tile but the candidates' (and the soft tap's lane):
+            //   rint(128 mu) by one FMA onto 1.5 * 2^23 (mu in [0, 1): the integer is the low mantissa bits, exact);
+            //   the window address carried instead of the window index; sign(o) from o's sign bit (o is never -0: the
+            //   accumulator starts at +0); sign(last) carried; hard decisions in a 32-bit word per half tile (<= 22
+            //   chips); the 2-bit advance codes as (dc << 2) + step in one 64-bit shift-add, the "- 1" of all codes at once.
+            auto mm_fast = [&]() {
+                if (!(ii < lim)) return;
+                const float kMagic = 12582912.0f;                       // 1.5 * 2^23
+                uint32_t woff = (ii - zorg) * 256u;                      // byte offset of the window in this lane's column
+                const uint32_t wlim = (lim - zorg) * 256u;
+                uint32_t h32 = 0u, step = 0u;
+                uint64_t dq = 0ull;
+                float tmu = kMagic;
+                float sl = __uint_as_float((__float_as_uint(last) & 0x80000000u) | 0x3f800000u);
+                const char* zc = reinterpret_cast<const char*>(zcol);
+                do {
+                    tmu = __builtin_fmaf(mu, 128.0f, kMagic);
+                    const uint32_t imu = __float_as_uint(tmu) - 0x4B400000u;
+                    const float4 ta = tapsA[imu], tb4 = tapsB[imu];
+                    const float* wv = reinterpret_cast<const float*>(zc + woff);
+                    float acc = 0.0f;
+                    acc = __builtin_fmaf(ta.x, wv[64 * 7], acc);
+                    acc = __builtin_fmaf(ta.y, wv[64 * 6], acc);
+                    acc = __builtin_fmaf(ta.z, wv[64 * 5], acc);
+                    acc = __builtin_fmaf(ta.w, wv[64 * 4], acc);
+                    acc = __builtin_fmaf(tb4.x, wv[64 * 3], acc);
+                    acc = __builtin_fmaf(tb4.y, wv[64 * 2], acc);
+                    acc = __builtin_fmaf(tb4.z, wv[64 * 1], acc);
+                    acc = __builtin_fmaf(tb4.w, wv[0], acc);
+                    const float o = acc;
+                    // h32 = 2 h32 + (o > 0): a compare and an add with carry
+                    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h32) : "v"(o) : "vcc");
+                    const float so = __uint_as_float((__float_as_uint(o) & 0x80000000u) | 0x3f800000u);
+                    const float mm = __builtin_fmaf(-so, last, sl * o);  // sl o - so last: so last is exact, one rounding
+                    last = o;
+                    sl = so;
+                    omega = omega + gain_omega * mm;
+                    {
+                        const float x = omega - omega_mid;
+                        const float c = 0.5f * (fabsf(x + omega_lim) - fabsf(x - omega_lim));
+                        omega = omega_mid + c;
+                    }
+                    mu = mu + omega + gain_mu * mm;
+                    const float fl = floorf(mu);
+                    step = fl >= 1.0f ? (uint32_t)(int)fl : 1u;
+                    mu = mu - fl;
+                    woff += step * 256u;
+                    dq = (dq << 2) + (uint64_t)step;
+                } while (woff < wlim);
+                const uint32_t cnt = (65u - (uint32_t)__builtin_clzll(dq)) >> 1;     // every 2-bit field is 1..3
+                ii = zorg + (woff >> 8);
+                t_last = (ii - step) * 128u + (__float_as_uint(tmu) - 0x4B400000u);
+                hist = (hist << cnt) | (uint64_t)h32;
+                dc = dq - (0x5555555555555555ull & ((1ull << (2u * cnt)) - 1ull));
+                nc += cnt;
+            };
+            if (tile == tb) mm_steps(std::true_type{});
+            else if (TAP) mm_steps(std::false_type{});
+            else mm_fast();
             dcode[hb >> 5] = dc;
             if (hb == 0u) nc_a = nc;
         }
@@ -1226,9 +1285,11 @@ __global__ __launch_bounds__(64) void zb_repair(
                 // up to the next symbol boundary without looking at the sink: one exit test per chip
                 uint32_t left = 32u - (uint32_t)s.chip_cnt;
                 uint32_t sh = s.shift;
+                // (zb_mm's shorter forms of the same arithmetic: rint(128 mu) by one FMA, the signs from the sign bits)
+                float sl = __uint_as_float((__float_as_uint(last) & 0x80000000u) | 0x3f800000u);
                 do {
-                    const int imu = (int)rintf(mu * 128.0f);
-                    if (ii * 128u + (uint32_t)imu + 128u >= hand_key) { handed = true; break; }
+                    const uint32_t imu = __float_as_uint(__builtin_fmaf(mu, 128.0f, 12582912.0f)) - 0x4B400000u;
+                    if (ii * 128u + imu + 128u >= hand_key) { handed = true; break; }
                     const float4 ta = tapsA[imu], tb4 = tapsB[imu];
                     const float* wv = &zcol[64u * (ii - zorg)];
                     float acc = 0.0f;
@@ -1241,8 +1302,10 @@ __global__ __launch_bounds__(64) void zb_repair(
                     acc = __builtin_fmaf(tb4.z, wv[64 * 1], acc);
                     acc = __builtin_fmaf(tb4.w, wv[0], acc);
                     const float o = acc;
-                    const float mm = (last < 0.0f ? -1.0f : 1.0f) * o - (o < 0.0f ? -1.0f : 1.0f) * last;
+                    const float so = __uint_as_float((__float_as_uint(o) & 0x80000000u) | 0x3f800000u);
+                    const float mm = __builtin_fmaf(-so, last, sl * o);
                     last = o;
+                    sl = so;
                     omega = omega + gain_omega * mm;
                     {
                         const float x = omega - omega_mid;
@@ -1253,7 +1316,7 @@ __global__ __launch_bounds__(64) void zb_repair(
                     const float fl = floorf(mu);
                     ii += fl >= 1.0f ? (uint32_t)(int)fl : 1u;
                     mu = mu - fl;
-                    sh = (sh << 1) | (o > 0.0f ? 1u : 0u);
+                    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(sh) : "v"(o) : "vcc");
                     left--;
                 } while (left != 0u && ii < lim);
                 const uint32_t took = 32u - (uint32_t)s.chip_cnt - left;
