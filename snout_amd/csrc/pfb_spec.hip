@@ -274,7 +274,7 @@ void pfb_spec(const PfbMfArgs A)
     __shared__ float atan_s[(ZB && !SNOUT_ATAN_PAIR) ? 257 : 1];
     __shared__ float2 atan_p[(ZB && SNOUT_ATAN_PAIR) ? 256 : 1];
     __shared__ double wts_s[ZB ? 64 : 1];
-    __shared__ float2 ylast[ZB ? kFftWaves : 1][ZB ? M : 1];
+    __shared__ float2 ylast[ZB ? kFftWaves + 1 : 1][ZB ? M : 1];       // (row kFftWaves: zeros, "the block before" of the first block)
     __shared__ float dls[ZB ? kFftWaves : 1][ZB ? M * 65 : 1];
 
     const uint32_t seg = blockIdx.x / A.segs.wgs_per_seg, bid = blockIdx.x - seg * A.segs.wgs_per_seg;
@@ -301,6 +301,7 @@ void pfb_spec(const PfbMfArgs A)
         if (SNOUT_ATAN_PAIR) { for (int i = t; i < 256; i += 64 * W) atan_p[i] = make_float2(A.zb.atan_tab[i], A.zb.atan_tab[i + 1]); }
         else { for (int i = t; i < 257; i += 64 * W) atan_s[i] = A.zb.atan_tab[i]; }
         if (t < 64) wts_s[t] = A.zb.iir_w[t];
+        if (t < M) ylast[kFftWaves][t] = make_float2(0.0f, 0.0f);
     }
 #ifdef SNOUT_MF_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -698,7 +699,7 @@ void pfb_spec(const PfbMfArgs A)
             for (int j = f / BPT; j < NTL; j += PERIOD, kblk++) {
                 const uint32_t tile = t_lo + (uint32_t)j;
                 const uint64_t m0b = (uint64_t)tile * T + 64u * (uint32_t)part;
-                const bool emit = tile >= t_begin;                   // the tile before the range only supplies y[m0 - 1]
+                const bool emit = __builtin_amdgcn_readfirstlane((int)(tile >= t_begin)) != 0;   // (wave-uniform) the tile before the range only supplies y[m0 - 1]
                 const uint64_t mg = m0b + mloc;
                 // ---- Q1: the row and the FFT; y_k[m] = (-1)^{km} X[k]
                 cx y[M];
@@ -742,25 +743,31 @@ void pfb_spec(const PfbMfArgs A)
                 if constexpr (ZB) {
                     if (l == 63) {
 #pragma unroll
-                        for (int k = 0; k < M; k++) ylast[f][k] = make_float2(re_of(y[k]), im_of(y[k]));
+                        for (int k = 0; k < M; k++) ylast[f][k] = make_float2(im_of(y[k]), re_of(y[k]));      // (im, re): see below
                     }
                 }
                 bar();
                 if constexpr (ZB) {
                     // y[m0 - 1]: of the block before this one (the wave before; wave 11's previous block for wave 0), zero
                     // in front of the very first block
+                    // (one unconditional broadcast read per channel: the row of zeros stands in where there is no block before)
                     const bool have_prev = j > 0 || part > 0;
-                    const float2* yp = &ylast[f == 0 ? kFftWaves - 1 : f - 1][0];
+                    const float2* yp = &ylast[!have_prev ? kFftWaves : (f == 0 ? kFftWaves - 1 : f - 1)][0];
                     const uint32_t left = n_out > m0b ? (uint32_t)(n_out - m0b < 64u ? n_out - m0b : 64u) : 0u;   // outputs of this block that exist
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
+                        // lane 0's y[m - 1] of the quarter's four channels in one go (stored (im, re): the shifted values then
+                        // sit in the register order the packed products take them in)
+                        float2 pv4[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) pv4[kk] = yp[4 * q + kk];
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) {
                             const int k = 4 * q + kk;
-                            const float2 pv = have_prev ? yp[k] : make_float2(0.0f, 0.0f);
+                            const float2 pv = pv4[kk];
                             float2 p;
-                            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.x), __float_as_int(re_of(y[k])), 0x138, 0xF, 0xF, false));
-                            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.y), __float_as_int(im_of(y[k])), 0x138, 0xF, 0xF, false));
+                            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.x), __float_as_int(im_of(y[k])), 0x138, 0xF, 0xF, false));
+                            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv.y), __float_as_int(re_of(y[k])), 0x138, 0xF, 0xF, false));
 #if SNOUT_ATAN_PAIR
                             float v = zb_discriminate_with(make_float2(re_of(y[k]), im_of(y[k])), p, AtanPairs{atan_p});
 #else

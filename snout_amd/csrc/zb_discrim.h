@@ -32,7 +32,11 @@ __device__ __forceinline__ float fast_atan2f_with(float y, float x, const Tab ta
     const int k = (int)a;
     float t0, t1;
     tab.get(k, t0, t1);
-    const float interp = t0 + (t1 - t0) * (a - (float)k);
+    // (t1 - t0 kept apart from a - k: the compiler otherwise packs the two subtractions into one v_pk_add_f32 that costs two
+    //  register moves to set up)
+    float dt;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(dt) : "v"(t1), "v"(t0));
+    const float interp = t0 + dt * (a - (float)k);
     const float base = z < 0.003921569f ? z : interp;
     const float PI = 3.14159265358979323846f, H = 1.57079632679489661923f;
     const bool xp = x >= 0.0f, yp = y >= 0.0f;
