@@ -1282,14 +1282,18 @@ __global__ __launch_bounds__(64) void zb_repair(
             const uint32_t zorg = r0 + hb - 8u;
             const uint32_t lim = alive && hi >= 8u ? hi - 7u : 0u;  // windows end inside what is staged
             while (ii < lim) {
-                // up to the next symbol boundary without looking at the sink: one exit test per chip
+                // up to the next symbol boundary without looking at the sink: ONE exit test per chip -- the hand-back test of
+                // the chip to come (its key needs rint(128 mu) of the updated mu, which the next step starts with anyway)
+                // is part of the loop condition, and looked at once more in front of the loop
+                float tmu = __builtin_fmaf(mu, 128.0f, 12582912.0f);
+                if (ii * 128u + (__float_as_uint(tmu) - 0x4B400000u) + 128u >= hand_key) { handed = true; alive = false; break; }
                 uint32_t left = 32u - (uint32_t)s.chip_cnt;
                 uint32_t sh = s.shift;
                 // (zb_mm's shorter forms of the same arithmetic: rint(128 mu) by one FMA, the signs from the sign bits)
                 float sl = __uint_as_float((__float_as_uint(last) & 0x80000000u) | 0x3f800000u);
+                uint32_t key;
                 do {
-                    const uint32_t imu = __float_as_uint(__builtin_fmaf(mu, 128.0f, 12582912.0f)) - 0x4B400000u;
-                    if (ii * 128u + imu + 128u >= hand_key) { handed = true; break; }
+                    const uint32_t imu = __float_as_uint(tmu) - 0x4B400000u;
                     const float4 ta = tapsA[imu], tb4 = tapsB[imu];
                     const float* wv = &zcol[64u * (ii - zorg)];
                     float acc = 0.0f;
@@ -1318,12 +1322,13 @@ __global__ __launch_bounds__(64) void zb_repair(
                     mu = mu - fl;
                     asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(sh) : "v"(o) : "vcc");
                     left--;
-                } while (left != 0u && ii < lim);
+                    tmu = __builtin_fmaf(mu, 128.0f, 12582912.0f);
+                    key = ii * 128u + (__float_as_uint(tmu) - 0x4B400000u) + 128u;
+                } while ((left != 0u) & (ii < lim) & (key < hand_key));
                 const uint32_t took = 32u - (uint32_t)s.chip_cnt - left;
                 more += took;
                 s.shift = sh;
                 s.chip_cnt += (int)took;
-                if (handed) { alive = false; break; }
                 if (left == 0u) {                                   // a whole symbol is in
                     const bool fin = sink_symbol(s, th, p->bytes);
                     if (fin) { ok = true; alive = false; break; }
