@@ -133,6 +133,12 @@ struct PfbZbTarget {
     uint64_t nsb;
     const float* atan_tab;
     const double* iir_w;
+    // Host-side bookkeeping of the rows' tails (ZbCtx::tails_*): the lanes read whole tiles, so what lies behind the last
+    // channelizer tile must be zero.  *dirty_to = the index from which every row of the buffer is known to be zero
+    // (~0: unknown); a launch that writes [0, done) with done >= *dirty_to leaves the tails as they are -- no fill
+    // kernel in front of the channelizer of every segment (round 5).  zero_rows: all rows of the buffer.
+    uint64_t* dirty_to = nullptr;
+    uint32_t zero_rows = 0;
 };
 
 // The segments of one channelizer launch (a batch of equal-length capture segments,
@@ -194,6 +200,7 @@ struct PfbCtx {
     uint64_t n_out_for(uint64_t n) const;
     // planes16 != null (M = 40): fused BTLE mode, hard bits go straight into the bit planes
     // zbt != null (M = 16): fused 802.15.4 mode, discriminator output goes straight to the Zigbee context
+    void zero_tails(const PfbZbTarget& zt, uint64_t done, uint32_t count, uint64_t d_seg, hipStream_t st);
     int run(const void* d_iq, uint64_t n, hipStream_t st, uint16_t* planes16 = nullptr,
             uint64_t plane_stride = 0, const PfbZbTarget* zbt = nullptr, int fmt = 0);
     // several equal-length segments in one launch (fused modes only), outputs k "seg" strides apart
@@ -217,7 +224,8 @@ struct ZbCtx {
     // discriminator output rows, tile records, per-lane stitch inputs, candidate keys,
     // first_owned|owned|offs|tsum|slot_total, chip streams
     DevBuf d_d, d_TR, d_lane_out, d_cand, d_lane_u32, d_stream;
-    DevBuf d_iirw, d_S, d_Lblk, d_lp_in;      // IIR carry-in: weights, sub-block sums, block sums, lane states
+    uint64_t tails_dirty_to = ~0ull, tails_stride = 0; uint32_t tails_rows = 0; void* tails_ptr = nullptr;     // see PfbZbTarget
+    DevBuf d_iirw, d_S, d_Lblk;               // IIR carry-in: weights, sub-block sums, block sums (folded per lane in zb_mm)
     DevBuf d_lane_end, d_snap, d_req;         // frame repair: every lane's loop at its core end, sinks busy at a seam, requests
     bool repair = true;                       // SNOUT_ZB_REPAIR=0: the lanes alone (rounds 1-4; A/B and tests only)
     uint32_t tail_prio = 3;                   // SNOUT_ZB_TAIL_PRIO: bit 0 zb_walk, bit 1 zb_repair run at s_setprio 3 (A/B)
@@ -235,7 +243,7 @@ struct ZbCtx {
     int enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
                       bool time_front, int fmt = 0);
     int enqueue_lanes(uint64_t n_channel_samples, hipStream_t st);     // IIR carry-in + zb_mm (behind enqueue_front's part)
-    PfbZbTarget pfb_target(uint32_t seg = 0) const;
+    PfbZbTarget pfb_target(uint32_t seg = 0);
     unsigned long long* seam_masks() const;         // per lane: XOR of the two timing loops' last 48 chips before its seam
     int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s, bool time_front);
     bool check_overflow(const ResultSlot& s);

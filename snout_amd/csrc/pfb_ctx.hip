@@ -29,6 +29,22 @@ __global__ __launch_bounds__(256) void zb_zero_tails(float* __restrict__ d, uint
     for (uint64_t i = done + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < d_stride; i += (uint64_t)gridDim.x * 256u) p[i] = 0.0f;
 }
 
+// The lanes read the discriminator rows in whole tiles: what lies behind the last channelizer tile (index `done` on) must be
+// zero.  The channelizer rewrites [0, done) of every row each time, so the tails stay zero from one segment to the next
+// unless this one is SHORTER than something written since they were zeroed (PfbZbTarget::dirty_to, kept by the owner of
+// the buffer): then -- and the first time -- one fill launch over all rows of the buffer.
+void PfbCtx::zero_tails(const PfbZbTarget& zt, uint64_t done, uint32_t count, uint64_t d_seg, hipStream_t st)
+{
+    const bool tracked = zt.dirty_to != nullptr && (count <= 1u || d_seg == (uint64_t)M * zt.d_stride);
+    if (tracked && done >= *zt.dirty_to) { *zt.dirty_to = done; return; }
+    if (done < zt.d_stride) {
+        const uint32_t rows = tracked ? std::max(zt.zero_rows, M * count) : M * count;
+        hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zt.d_stride - done, 256), 16u), rows), dim3(256), 0, st,
+                           zt.d, tracked ? (uint64_t)M * zt.d_stride : d_seg, zt.d_stride, done, M);
+    }
+    if (zt.dirty_to) *zt.dirty_to = tracked ? done : ~0ull;
+}
+
 int PfbCtx::init(uint32_t M_, uint32_t n_cus_, uint32_t reserved_)
 {
     M = M_;
@@ -123,12 +139,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
         const uint32_t wgs = std::max(1u, (grid_blocks ? grid_blocks : resident) / count);
         const uint32_t tpw = cdiv(n_tiles, wgs), nwg = cdiv(n_tiles, tpw);
         segs.wgs_per_seg = nwg;
-        if (zbt) {
-            const uint64_t done = (uint64_t)n_tiles * T;
-            if (done < zbt->d_stride)
-                hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zbt->d_stride - done, 256), 16u), M * count), dim3(256), 0, st,
-                                   zbt->d, d_seg, zbt->d_stride, done, M);
-        }
+        if (zbt) zero_tails(*zbt, (uint64_t)n_tiles * T, count, d_seg, st);
         PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), mode == 0 ? d_y.as<float2>() : nullptr, y_stride,
                     planes16, plane_stride, zb};
         last_kernel = use_valu ? kKernelValu : kKernelMfma;
@@ -158,13 +169,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     per_seg = cdiv(n_tiles, tpw);                           // every range non-empty
     segs.wgs_per_seg = per_seg;
     const uint32_t grid = per_seg * count;
-    if (zbt) {
-        // rows are read in whole lane tiles: zero what lies behind the last channelizer tile
-        const uint64_t done = (uint64_t)n_tiles * T;
-        if (done < zbt->d_stride)
-            hipLaunchKernelGGL(zb_zero_tails, dim3((uint32_t)std::min<uint64_t>(cdiv(zbt->d_stride - done, 256), 16u), M * count), dim3(256), 0, st,
-                               zbt->d, d_seg, zbt->d_stride, done, M);
-    }
+    if (zbt) zero_tails(*zbt, (uint64_t)n_tiles * T, count, d_seg, st);
     PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), mode == 0 ? d_y.as<float2>() : nullptr,
                 y_stride, planes16, plane_stride, zb};
     last_kernel = waves == 12 ? kKernelSpec12 : kKernelSpec;

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint64_t tr_index(uint32_t w, uint32_t nt, uint32_t t
 // first lane's from its own load); rows beyond n up to the padded stride are written as zeros so
 // that every lane of zb_mm may read whole tiles.  Each 64-sample sub-block also yields S_j, the
 // zero-state response of the single-pole IIR to its samples (double, fixed order), from which
-// zb_iir_fold / zb_iir_scan build every lane's initial filter state (the "IIR carry-in", see the
+// zb_iir_fold and zb_mm's prologue build every lane's initial filter state (the "IIR carry-in", see the
 // oracle): four threads per sub-block sum 16 terms each in sequence, S = (P0 + P1) + (P2 + P3).
 constexpr uint32_t kDiscChunks = 4;     // 1024-sample chunks per zb_discrim block
 
@@ -142,21 +142,6 @@ __global__ __launch_bounds__(256) void zb_iir_fold(const double* __restrict__ S,
     Lblk[g] = L;
 }
 
-// lp_in[l] = fold of the W = ceil(2^18 / core) lane blocks before lane l, from 0 (older samples have
-// decayed below 2^-60; see the oracle): one thread per lane, no dependence between lanes.
-__global__ __launch_bounds__(256) void zb_iir_scan(const double* __restrict__ Lblk, uint32_t lanes_per_slot,
-                                                  uint32_t total_lanes, uint32_t window, double dfirst,
-                                                  double dcore, double* __restrict__ lp_in)
-{
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= total_lanes) return;
-    const uint32_t li = g % lanes_per_slot;
-    const double* L = Lblk + (g - li);
-    double lp = 0.0;
-    for (uint32_t i = li > window ? li - window : 0u; i < li; i++) lp = (i == 0u ? dfirst : dcore) * lp + L[i];
-    lp_in[g] = lp;
-}
-
 // ---------------------------------------------------------------------------------------------
 // a5-a6: lanes (IIR + Mueller & Mueller), chips out.
 // ---------------------------------------------------------------------------------------------
@@ -201,7 +186,7 @@ template <bool TAP>
 __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     const float* __restrict__ d, uint64_t d_stride, uint64_t n, uint32_t nt, uint32_t lanes_per_slot,
     uint32_t total_lanes, uint32_t core, uint32_t warmup, const float* __restrict__ mmse,
-    const double* __restrict__ lp_in,
+    const double* __restrict__ Lblk, uint32_t window, double dfirst, double dcore,
     uint32_t* __restrict__ TR, ZbLaneOut* __restrict__ lane_out, ZbLaneEnd* __restrict__ lane_end,
     uint32_t* __restrict__ cand_keys,
     float* __restrict__ soft_z, float* __restrict__ soft_chips, uint32_t soft_lane, uint32_t soft_cap,
@@ -232,7 +217,15 @@ __global__ __launch_bounds__(kMmWaves * 64) void zb_mm(
     const double alpha = 0.00016, one_minus = 1.0 - 0.00016;
     const float omega_mid = 2.0f, gain_omega = 0.000225f, gain_mu = 0.03f;
     const float omega_lim = omega_mid * 0.0002f;
-    double lp = active ? lp_in[g] : 0.0;
+    // The filter state at the lane's first sample (the "IIR carry-in"): the fold of the W = ceil(2^18 / core) lane
+    // blocks before this lane, from 0 -- older samples have decayed below 2^-60, see the oracle.  (Round 5: here instead of
+    // in a kernel of its own between zb_iir_fold and this one: one launch and its gap less in front of every segment's
+    // lanes; ~40 dependent multiply-adds per lane.)
+    double lp = 0.0;
+    if (active) {
+        const double* L = Lblk + (g - li);
+        for (uint32_t i = li > window ? li - window : 0u; i < li; i++) lp = (i == 0u ? dfirst : dcore) * lp + L[i];
+    }
     double lp_rce = lp;
     float mu = 0.5f, omega = 2.0f, last = 0.0f;
     uint32_t ii = 0, n_chips = 0, t_last = 0, c0 = 0, cand_n = 0;
@@ -1597,7 +1590,7 @@ void ZbCtx::destroy()
     d_atan.release(); d_mmse.release(); d_slot_channel.release();
     d_d.release(); d_TR.release(); d_lane_out.release(); d_cand.release(); d_lane_u32.release();
     d_stream.release(); d_stage.release(); d_lane_cnt.release(); d_soft.release();
-    d_iirw.release(); d_S.release(); d_Lblk.release(); d_lp_in.release();
+    d_iirw.release(); d_S.release(); d_Lblk.release();
     d_lane_end.release(); d_snap.release(); d_req.release();
 }
 
@@ -1645,7 +1638,6 @@ int ZbCtx::reserve(uint64_t n, uint32_t segs)
     nsb = (n + 63u) / 64u;
     if (int rc = d_S.ensure(nsb * n_slots * 8u)) return rc;
     if (int rc = d_Lblk.ensure((uint64_t)total_lanes * 8u)) return rc;
-    if (int rc = d_lp_in.ensure((uint64_t)total_lanes * 8u)) return rc;
     if (int rc = d_lane_end.ensure((uint64_t)total_lanes * sizeof(ZbLaneEnd))) return rc;
     if (int rc = d_snap.ensure((uint64_t)total_lanes * sizeof(ZbSnap))) return rc;
     if (int rc = d_req.ensure(((uint64_t)total_lanes + 1u) * 4u)) return rc;
@@ -1728,7 +1720,7 @@ int ZbCtx::soft(uint32_t stage_id, uint32_t lane, uint64_t n, float* out, uint64
     uint32_t* sn = (uint32_t*)(d_soft.as<float>() + 2 * kSoftCap);
     // re-run the lanes with the tap on (rewrites identical tile records)
     hipLaunchKernelGGL(zb_mm<true>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, nullptr, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
-                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
+                       total_lanes, core, warmup, d_mmse.as<float>(), d_Lblk.as<double>(), ((1u << 18) + core - 1u) / core, dfirst, dcore,
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_lane_end.as<ZbLaneEnd>(), d_cand.as<uint32_t>(),
                        sz, sc, lane, (uint32_t)kSoftCap, sn);
     SNOUT_HIP(hipDeviceSynchronize());
@@ -1789,11 +1781,8 @@ int ZbCtx::enqueue_lanes(uint64_t n, hipStream_t st)
     if (n < 9u) return 0;
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
-    hipLaunchKernelGGL(zb_iir_scan, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_Lblk.as<double>(),
-                       lanes_per_slot, total_lanes, ((1u << 18) + core - 1u) / core, dfirst, dcore,
-                       d_lp_in.as<double>());
     hipLaunchKernelGGL(zb_mm<false>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
-                       total_lanes, core, warmup, d_mmse.as<float>(), d_lp_in.as<double>(),
+                       total_lanes, core, warmup, d_mmse.as<float>(), d_Lblk.as<double>(), ((1u << 18) + core - 1u) / core, dfirst, dcore,
                        d_TR.as<uint32_t>(), d_lane_out.as<ZbLaneOut>(), d_lane_end.as<ZbLaneEnd>(), d_cand.as<uint32_t>(),
                        (float*)nullptr, (float*)nullptr, 0xFFFFFFFFu, 0u, (uint32_t*)nullptr);
     SNOUT_HIP(hipGetLastError());
@@ -1806,10 +1795,16 @@ unsigned long long* ZbCtx::seam_masks() const
     return reinterpret_cast<unsigned long long*>(d_lane_u32.as<uint32_t>() + ((words + 1u) & ~1ull));
 }
 
-PfbZbTarget ZbCtx::pfb_target(uint32_t seg) const
+PfbZbTarget ZbCtx::pfb_target(uint32_t seg)
 {
+    // the rows' tails are known to be zero only for the buffer, the row length and the rows they were zeroed for
+    if (d_d.p != tails_ptr || d_stride != tails_stride || n_slots > tails_rows) {
+        tails_dirty_to = ~0ull;
+        tails_ptr = d_d.p; tails_stride = d_stride; tails_rows = n_slots;
+    }
     return PfbZbTarget{d_d.as<float>() + (uint64_t)seg * seg_slots * d_stride, d_stride,
-                       d_S.as<double>() + (uint64_t)seg * seg_slots * nsb, nsb, d_atan.as<float>(), d_iirw.as<double>()};
+                       d_S.as<double>() + (uint64_t)seg * seg_slots * nsb, nsb, d_atan.as<float>(), d_iirw.as<double>(),
+                       seg == 0 ? &tails_dirty_to : nullptr, tails_rows};
 }
 
 // Tail (stitch, a7, ordered compaction into s.d_out / s.d_totals) on the handle's tail stream, so

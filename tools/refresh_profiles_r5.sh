@@ -21,7 +21,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- $
 python3 $R/tools/timeline.py $O/cfg5 --marker "pfb_spec<40" --last 6 --per 1 --list 9 > $O/cfg5_timeline.txt 2>&1
 # cfg #4 pipelined (the frame repair and zb_walk beside the next segment's channelizer)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4_pipe -- $B --workload cfg4 --steps 10 --no-cpu > $O/cfg4_pipe.log 2>&1
-python3 $R/tools/timeline.py $O/cfg4_pipe --marker "pfb_spec<16" --last 6 --per 1 --until-marker --list 9 > $O/cfg4_timeline.txt 2>&1
+python3 $R/tools/timeline.py $O/cfg4_pipe --marker "pfb_spec<16" --last 6 --per 1 --skip 3 --list 9 > $O/cfg4_timeline.txt 2>&1
 # rank 0's load of eight ranks rehearsed at world 1 (RCCL backend): step inflation of the headline workload and of cfg #5
 bash $R/tools/r4_fake_world.sh > $O/fake_world.txt 2>&1
 # SQ counters of the channelizer (three passes)

@@ -5,7 +5,8 @@ who runs alone, and (--list N) the launches of the last N ms in order with the i
     python3 tools/timeline.py <dir with *kernel_trace.csv> --marker 'pfb_spec<40' --last 6 [--per 2] [--list 12]
 
 The window starts at the (last x per)-th from last launch of the marker kernel (`per` launches of it per step) and ends
-with the last kernel of the trace (pass --until-marker to end at the marker's last launch instead)."""
+with the last kernel of the trace (pass --until-marker to end at the marker's last launch instead, --skip N to leave out
+the last N marker launches first)."""
 import argparse
 import collections
 import csv
@@ -18,6 +19,7 @@ ap.add_argument("--marker", default="pfb_spec<40")
 ap.add_argument("--last", type=int, default=6, help="steps in the window")
 ap.add_argument("--per", type=int, default=1, help="marker launches per step")
 ap.add_argument("--until-marker", action="store_true")
+ap.add_argument("--skip", type=int, default=0, help="leave out the last N marker launches (what a bench runs after its timed loop); implies --until-marker")
 ap.add_argument("--list", type=float, default=0.0, help="list the launches of the last N ms of the window")
 a = ap.parse_args()
 f = sorted(glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True))[-1]
@@ -26,6 +28,9 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].spli
        r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows]
 ev.sort()
 mk = [e[0] for e in ev if a.marker in e[2]]
+if a.skip:
+    mk = mk[:len(mk) - a.skip]
+    a.until_marker = True
 need = a.last * a.per
 if len(mk) < need + 1:
     raise SystemExit("only %d launches of %r in the trace" % (len(mk), a.marker))
