@@ -878,7 +878,7 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and args.workload is None and not args.no_others:
             others = {}
-            k = max(3, min(args.steps, 10))
+            k = max(3, min(args.steps, 20))         # as many steps as the headline by default: the pipeline's fill and drain are inside the timed region
             for name in ("cfg2", "cfg4", "zigbee1"):
                 nn = int(WORKLOADS[name][3])
                 r, _ = run_workload(name, nn, k, 1, device, 0, 1, checks=not args.no_cpu,
@@ -890,13 +890,13 @@ def main():
                                                   "frames_lost_vs_sequential")}
                 if "fp32" in r:
                     others[name]["fp32_frac"] = r["fp32"]["frac"]
-            r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, 0, 1, seconds=args.seconds, parity=not args.no_cpu)
+            r5 = run_cfg5(k, 3, device, 0, 1, seconds=args.seconds, parity=not args.no_cpu)
             others["cfg5"] = {f: r5[f] for f in CFG5_FIELDS if f in r5}
             others["cfg5"]["note"] = "BASELINE.json configs[4] on one GPU; `--gpus N` carries its N-rank point the same way"
             out["other_workloads"] = others
         elif world > 1 and args.workload is None and not args.no_others:
             # configs[4] on the N ranks: segments round-robin, per-step RCCL all_gather of the records, dedup on rank 0
-            r5 = run_cfg5(max(3, min(args.steps, 10)), 3, device, rank, world, seconds=args.seconds)
+            r5 = run_cfg5(max(3, min(args.steps, 20)), 3, device, rank, world, seconds=args.seconds)
             if rank == 0:
                 out["other_workloads"] = {"cfg5": {f: r5[f] for f in CFG5_FIELDS if f in r5}}
     if dist.is_initialized():
