@@ -32,7 +32,8 @@ extern "C" {
 
 /* 3: the 802.15.4 frame repair (snout_pkt.flags SNOUT_PKT_ZB_REPAIRED) and ONE default lane shape, 6144 / 1024, whatever the size
  *    of a call (snout_zigbee_lane_shape ignores its argument): the records of a capture no longer depend on how it is cut
- *    into submissions, and the default decode is within 1 % of the one sequential receiver's frames on dense traffic
+ *    into submissions, and the default decode loses <= 1 % of the one sequential receiver's frames on dense traffic and
+ *    finds 1-2 % that it misses (measured per run: bench.py frames_lost_vs_sequential)
  * 2: snout_rx_pack_last_records(skip, longest_dev), SNOUT_CFG_RECORDS_ON_DEVICE, batches of up to 64 segments,
  *    snout_pkt.flags SNOUT_PKT_ZB_SEAM_DISAGREED, snout_zigbee_lane_shape (the default 802.15.4 lane shape depends on the
  *    size of the call), the bench aid moved to snout_bench.h -- a client built against version 1 fails the handshake in
@@ -91,10 +92,10 @@ typedef struct snout_rx_cfg {
     uint32_t access_addr;     /* BTLE `-a` (btle.py:66); 0 -> 0x8E89BED6                         */
     uint32_t crc_init;        /* BTLE `-k` (btle.py:67); 0 -> 0x555555                           */
     uint32_t chip_threshold;  /* packet_sink(threshold) (top_block.py:67); 0 -> 10               */
-    uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 -> 2048           */
-    uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 -> 512;
+    uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 (with zb_warmup != 0) -> 2048 */
+    uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 (with zb_core != 0) -> 512;
                                  multiples of 64, warm-up < core; the timing loop needs >= 256.
-                                 BOTH 0: the default shape, core 6144 / warm-up 1024 (snout_zigbee_lane_shape),
+                                 BOTH 0 (the default): core 6144 / warm-up 1024 (snout_zigbee_lane_shape),
                                  the same for every call of every handle.  The decoded frame set is a function
                                  of the shape and of where the calls cut the capture;
                                  zb_core >= the call's channel samples is the reference's one sequential loop  */
@@ -136,7 +137,7 @@ typedef struct snout_pkt {
     uint8_t  crc_ok;          /* BTLE: 1 if CRC24 matches (btle_rx prints CRC0). Zigbee: FCS-16 ok */
     uint8_t  lqi;             /* Zigbee LQI as packet_sink computes it; BTLE 0                   */
     uint8_t  pdu_type;        /* BTLE header & 0x0F                                              */
-    uint8_t  flags;           /* BTLE: TxAdd | RxAdd<<1.  Zigbee: SNOUT_PKT_ZB_SEAM_DISAGREED              */
+    uint8_t  flags;           /* BTLE: TxAdd | RxAdd<<1.  Zigbee: SNOUT_PKT_ZB_SEAM_DISAGREED | SNOUT_PKT_ZB_REPAIRED */
     uint32_t aux;             /* BTLE: sample phase 0..3 of the hit; Zigbee: lane id             */
     uint8_t  bytes[136];
 } snout_pkt;

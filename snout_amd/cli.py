@@ -87,7 +87,11 @@ def _source(proto, iq, synthetic, channels, seconds, fmt="cf32", wideband=False,
         if iq:
             import os
             import stat
-            if iq == "-" or not stat.S_ISREG(os.stat(iq).st_mode):
+            try:
+                regular = iq != "-" and stat.S_ISREG(os.stat(iq).st_mode)
+            except OSError as e:
+                raise click.UsageError(f"--iq {iq}: {e.strerror}")
+            if not regular:
                 raise click.UsageError("--wideband / --sharded read a capture FILE (live streams -- '-', a FIFO, a device -- "
                                        "are implemented for the single-channel scans only)")
             return WidebandSource(iq, pid, FORMATS[fmt], segment=segment, sharded=sharded, batch=batch)
@@ -114,7 +118,10 @@ def _file_or_stream(iq: str, fmt: int):
     import stat
     if iq == "-":
         return StreamSource("-", fmt)
-    mode = os.stat(iq).st_mode
+    try:
+        mode = os.stat(iq).st_mode
+    except OSError as e:
+        raise click.UsageError(f"--iq {iq}: {e.strerror}")
     if stat.S_ISFIFO(mode) or stat.S_ISCHR(mode) or stat.S_ISSOCK(mode):
         return StreamSource(iq, fmt)
     return FileSource(iq, fmt)
@@ -192,7 +199,8 @@ def zigbee():
 @click.option("--lane-core", type=int, default=0,
               help="clock-recovery lane length in channel samples (multiple of 64; 0: the default shape, 6144 with warm-up 1024). The "
                    "reference's receiver is ONE sequential loop: a lane at least as long as the capture is that loop (DESIGN.md 6-3)")
-@click.option("--lane-warmup", type=int, default=0, help="samples a lane's timing loop starts before its core (multiple of 64; 0: 512)")
+@click.option("--lane-warmup", type=int, default=0, help="samples a lane's timing loop starts before its core (multiple of 64; 0 with --lane-core 0: 1024, the default shape; "
+                   "0 with a --lane-core: 512)")
 def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, batch, filename, iq, fmt, synthetic,
                 seconds, udp, lane_core, lane_warmup):
     chs = parse_channels(channels, "zigbee")

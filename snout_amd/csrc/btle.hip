@@ -18,6 +18,7 @@
 // Roofline: btle_demod_corr is HBM-bound, 8 B read per complex sample (+1/64 warm-up re-read,
 // +0.125 B/sample plane write). Everything after it is O(candidates).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "iq_fmt.h"
 
 namespace snout {
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(256) void btle_demod_corr(
 // a1 for channelized input: correlate over bit planes already in HBM.  One wave per
 // (slot, chunk); per iteration, lane l tests the window ending at symbol l of each phase.
 // ---------------------------------------------------------------------------------------------
+// (Round 6, measured and dropped: a grid-stride form -- 1024 / 2048 / 4096 workgroups, the next item's plane words requested
+//  before the current ones are looked at -- 93 / 85 / 80 us against 80 us for one short wave per item: the kernel is bound
+//  by its ~300 VALU instructions per 16 384 symbols x 4 phases, not by the rate its 97 656 waves are dispatched at.  What
+//  doubled it in round 5 was the number of streams the handle had created, profiles/r6_streams.md.)
 __global__ __launch_bounds__(256) void btle_corr_planes(
     const uint64_t* __restrict__ planes, uint64_t plane_stride, uint64_t nb, uint32_t aa,
     uint32_t n_chunks, uint32_t n_slots, uint32_t* __restrict__ chunk_cnt,
@@ -713,11 +718,11 @@ int BtleCtx::launch_demod_corr(const void* d_iq, uint64_t n, uint64_t iq_stride,
 }
 
 // Wideband front end already filled planes: correlate them.
-int BtleCtx::launch_corr_planes(uint64_t n, hipStream_t st)
+int BtleCtx::launch_corr_planes(uint64_t n, hipStream_t st, hipEvent_t ev_stop)
 {
-    hipLaunchKernelGGL(btle_corr_planes, dim3(cdiv((uint64_t)n_chunks * n_slots, 4)), dim3(256), 0, st,
-                       d_planes.as<uint64_t>(), plane_stride, n - 4u, aa, n_chunks, n_slots,
-                       d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap);
+    hipExtLaunchKernelGGL(btle_corr_planes, dim3(cdiv((uint64_t)n_chunks * n_slots, 4)), dim3(256), 0, st, nullptr, ev_stop, 0,
+                          (const uint64_t*)d_planes.as<uint64_t>(), plane_stride, n - 4u, aa, n_chunks, n_slots,
+                          d_chunk_cnt.as<uint32_t>(), d_chunk_hits.as<uint32_t>(), hit_cap);
     SNOUT_HIP(hipGetLastError());
     return 0;
 }

@@ -107,7 +107,7 @@ struct BtleCtx {
     int reserve(uint64_t n_channel_samples, uint32_t segs = 1);
     int launch_demod_corr(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st,
                           ResultSlot* timing, int fmt = 0);
-    int launch_corr_planes(uint64_t n, hipStream_t st);
+    int launch_corr_planes(uint64_t n, hipStream_t st, hipEvent_t ev_stop = nullptr);     // ev_stop: bound to the kernel's dispatch
     // hit lists -> ordered records in s.d_out, totals in s.d_totals (no host sync)
     int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s);
     // inspect the totals of a finished slot; true if capacity was exceeded (and grows it)
@@ -179,7 +179,7 @@ int pfb_mfma_launch(uint32_t M, bool btle, int fmt, int impl, uint32_t grid, hip
 
 // pfb_spec.hip: one workgroup of specialised waves per CU (FIR + staging | FFT in registers), M = 40 and 16
 uint32_t pfb_spec_tile(uint32_t M);      // output times per tile of the pfb_spec kernel for M channels
-int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // mode: 0 channel IQ, 1 BTLE planes, 2 802.15.4 rows; waves: 12 or 16 per workgroup (M = 40)
+int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // mode: 0 channel IQ, 1 BTLE planes, 2 802.15.4 rows; waves: 12 or 16 per workgroup (M = 40)
 
 struct PfbCtx {
     uint32_t M = 0;
@@ -192,8 +192,9 @@ struct PfbCtx {
                                      // leave room for other streams' kernels; pfb_spec.hip's one 16-wave workgroup per CU does not)
     int impl = 4;                    // SNOUT_PFB_IMPL, M = 40 kernel: 0 valu = pfb.hip, 1 mfma / 2 spec16 = pfb_mfma.hip with its FIR on the matrix / vector pipe, 3 spec12 / 4 spec = pfb_spec.hip with 12 / 16 waves
     DevBuf d_proto, d_tw, d_tw5, d_y;
-    bool gate = false;               // SNOUT_PFB_GATE=1 (A/B): every handle's channelizer launches go through one shared stream
-    hipEvent_t ev_gate_in = nullptr, ev_gate_out = nullptr;
+    // events of the NEXT launch (cleared by it): bound to the kernel's own dispatch (hipExtLaunchKernel) instead of being
+    // recorded as barrier packets of their own between two front-end kernels
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     uint32_t min_item_tiles = 48;    // SNOUT_PFB_MIN_ITEM: fewest tiles of one workgroup's range when a batch is cut finer than one range per CU
     int init(uint32_t M, uint32_t n_cus = 256, uint32_t reserved_cus = 0);
     void destroy();

@@ -52,7 +52,6 @@ int PfbCtx::init(uint32_t M_, uint32_t n_cus_, uint32_t reserved_)
     reserved_cus = reserved_ < n_cus ? reserved_ : n_cus - 1u;
     if (M != 40 && M != 16) { set_last_error("channelizer supports M = 40 or 16, not %u", M); return SNOUT_EINVAL; }
     if (const char* e = getenv("SNOUT_PFB_BLOCKS")) grid_blocks = (uint32_t)atoi(e);
-    if (const char* e = getenv("SNOUT_PFB_GATE")) gate = atoi(e) != 0;
     if (const char* e = getenv("SNOUT_PFB_MIN_ITEM")) min_item_tiles = std::max(1u, (uint32_t)atoi(e));
     if (const char* e = getenv("SNOUT_PFB_IMPL")) {
         // the kernel actually launched is recorded per launch (last_kernel); an unknown name is an error, not the default
@@ -173,21 +172,9 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), mode == 0 ? d_y.as<float2>() : nullptr,
                 y_stride, planes16, plane_stride, zb};
     last_kernel = waves == 12 ? kKernelSpec12 : kKernelSpec;
-    if (gate) {
-        // One persistent channelizer at a time in the process (A/B switch SNOUT_PFB_GATE=1): the launch goes to a stream
-        // that every handle's channelizer shares, between two events of the caller's stream.  Two scans on one GPU (cfg #5)
-        // otherwise run their channelizers side by side on half the CUs each.
-        static hipStream_t g_chan = nullptr;
-        if (!g_chan) SNOUT_HIP(hipStreamCreateWithFlags(&g_chan, hipStreamNonBlocking));
-        if (!ev_gate_in) { SNOUT_HIP(hipEventCreateWithFlags(&ev_gate_in, hipEventDisableTiming)); SNOUT_HIP(hipEventCreateWithFlags(&ev_gate_out, hipEventDisableTiming)); }
-        SNOUT_HIP(hipEventRecord(ev_gate_in, st));
-        SNOUT_HIP(hipStreamWaitEvent(g_chan, ev_gate_in, 0));
-        if (int rc = pfb_spec_launch(M, mode, fmt, waves, grid, g_chan, a)) return rc;
-        SNOUT_HIP(hipEventRecord(ev_gate_out, g_chan));
-        SNOUT_HIP(hipStreamWaitEvent(st, ev_gate_out, 0));
-        return 0;
-    }
-    return pfb_spec_launch(M, mode, fmt, waves, grid, st, a);
+    hipEvent_t e0 = ev_start, e1 = ev_stop;
+    ev_start = ev_stop = nullptr;
+    return pfb_spec_launch(M, mode, fmt, waves, grid, st, a, e0, e1);
 }
 
 }  // namespace snout

@@ -27,6 +27,7 @@
 //   FIR and FFT waves over the four SIMDs.  (A 12-wave layout with 16 outputs per FIR thread and one idle wave is kept
 //   as an A/B partner: SNOUT_PFB_IMPL=spec12.)
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "iq_fmt.h"
 #include "zb_discrim.h"
 #include <type_traits>
@@ -824,13 +825,14 @@ extern "C" int snout_debug_sp_stamps(unsigned long long* out, uint32_t n)
 
 uint32_t pfb_spec_tile(uint32_t M) { return M == 40 ? (uint32_t)sp::Layout<40, 16>::T : (uint32_t)sp::Layout<16, 16>::T; }
 
-int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a)
+int pfb_spec_launch(uint32_t M, int mode, int fmt, int waves, uint32_t grid, hipStream_t st, const PfbMfArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
+    // (hipExtLaunchKernelGGL: the stop event is the kernel's own completion signal -- no barrier packet behind the kernel)
 #define SNOUT_SP(MM, MODE, WW)                                                                             \
     do {                                                                                                  \
-        if (fmt == kFmtSc8) hipLaunchKernelGGL((pfb_spec<MM, MODE, kFmtSc8, WW>), dim3(grid), dim3(64 * WW), 0, st, a);        \
-        else if (fmt == kFmtSc16) hipLaunchKernelGGL((pfb_spec<MM, MODE, kFmtSc16, WW>), dim3(grid), dim3(64 * WW), 0, st, a); \
-        else hipLaunchKernelGGL((pfb_spec<MM, MODE, kFmtCf32, WW>), dim3(grid), dim3(64 * WW), 0, st, a);                      \
+        if (fmt == kFmtSc8) hipExtLaunchKernelGGL((pfb_spec<MM, MODE, kFmtSc8, WW>), dim3(grid), dim3(64 * WW), 0, st, ev_start, ev_stop, 0, a);        \
+        else if (fmt == kFmtSc16) hipExtLaunchKernelGGL((pfb_spec<MM, MODE, kFmtSc16, WW>), dim3(grid), dim3(64 * WW), 0, st, ev_start, ev_stop, 0, a); \
+        else hipExtLaunchKernelGGL((pfb_spec<MM, MODE, kFmtCf32, WW>), dim3(grid), dim3(64 * WW), 0, st, ev_start, ev_stop, 0, a);                      \
     } while (0)
     if (M == 40 && mode != kSpZb) {
         if (waves == 12) { if (mode == kSpBtle) SNOUT_SP(40, kSpBtle, 12); else SNOUT_SP(40, kSpIq, 12); }

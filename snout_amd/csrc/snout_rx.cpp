@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <new>
+#include <algorithm>
 
 namespace snout {
 
@@ -103,7 +104,9 @@ struct snout_rx {
     BtleCtx btle, btle2, btle3;
     ZbCtx zb2, zb3;           // (second and third Zigbee work set; the first is `zb`)
     hipStream_t tail_streams[3] = {nullptr, nullptr, nullptr};
-    bool one_tail = false;    // SNOUT_ONE_TAIL=1 (A/B): every work set's tail on one stream, as in rounds 1-4
+    uint32_t zb_split = 0;    // wideband 802.15.4: CUs the channelizer's grid leaves to the lanes (0: lanes behind the channelizer)
+    bool ext_launch = true;   // SNOUT_EXT_LAUNCH=0 (A/B): events around the front-end kernels as recorded barrier packets
+    int n_tails = 1;          // tail streams CREATED (SNOUT_TAIL_STREAMS overrides): work set k's tail runs on stream k % n_tails
     bool sync_call = false;   // inside snout_rx_process*: nothing to overlap, the tail stays on the caller's stream
     ZbCtx zb;
     PfbCtx pfb;
@@ -156,7 +159,7 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
     // -> 9.9 ms); behind a 1e9-sample front end the separate stream is worth 5 %.
     const uint64_t ch_samples = (h->wide ? h->pfb.n_out_for(s.n_in) * h->cfg.n_channels : s.n_in) * s.segs.count;
     const bool inline_tail = h->sync_call || (h->cfg.proto == SNOUT_PROTO_BTLE && ch_samples < (1ull << 26));
-    hipStream_t tail = inline_tail ? st : h->tail_streams[h->one_tail ? 0 : s.work_set];
+    hipStream_t tail = inline_tail ? st : h->tail_streams[s.work_set % h->n_tails];
     // (the first kernel's start event ev_k0 also marks the start of the segment: every event on the
     //  caller's stream is a barrier packet, so there is no separate one)
     // the tail that last used this work set must be done; usually it is, and a wait that is not
@@ -177,7 +180,11 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
             if (int rc = z.reserve(n_ch, s.segs.count)) return rc;
             zt = z.pfb_target();
         }
-        SNOUT_HIP(hipEventRecord(s.ev_k0, st));
+        // ext_launch: the channelizer's stop event and the correlator's "front end done" event ride on the kernels' own
+        // dispatches (hipExtLaunchKernel) -- every hipEventRecord on the caller's stream is a barrier packet of its own
+        // between two front-end kernels (SNOUT_EXT_LAUNCH=0: recorded events, rounds 1-5)
+        if (h->ext_launch) { h->pfb.ev_start = s.ev_k0; h->pfb.ev_stop = s.ev_k1; }
+        else SNOUT_HIP(hipEventRecord(s.ev_k0, st));
         if (s.segs.count > 1) {
             // a batch: every segment's channelizer pass in one launch, outputs one segment stride apart
             if (fused) {
@@ -191,19 +198,21 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         } else if (int rc = h->pfb.run(s.iq, s.n_in, st, fused ? bw.d_planes.as<uint16_t>() : nullptr,
                                        bw.plane_stride, (fused_zb && n_ch >= 9u) ? &zt : nullptr, ch_fmt)) return rc;
         ch_fmt = 0;
-        SNOUT_HIP(hipEventRecord(s.ev_k1, st));
+        if (!h->ext_launch) SNOUT_HIP(hipEventRecord(s.ev_k1, st));
         ch_iq = (fused_zb && n_ch >= 9u) ? nullptr : h->pfb.d_y.as<float>();
         ch_stride = h->pfb.y_stride;
     }
     if (h->cfg.proto == SNOUT_PROTO_BTLE) {
         BtleCtx& b = btle_of(h, s);
         if (int rc = b.reserve(n_ch, s.segs.count)) return rc;
+        bool front_bound = false;
         if (fused) {
-            if (int rc = b.launch_corr_planes(n_ch, st)) return rc;       // bits are already in the planes
+            front_bound = h->ext_launch;
+            if (int rc = b.launch_corr_planes(n_ch, st, front_bound ? s.ev_front : nullptr)) return rc;       // bits are already in the planes
         } else {
             if (int rc = b.launch_demod_corr(ch_iq, n_ch, ch_stride, st, h->wide ? nullptr : &s, ch_fmt)) return rc;
         }
-        if (!nb_btle) SNOUT_HIP(hipEventRecord(s.ev_front, st));
+        if (!nb_btle && !front_bound) SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, nb_btle ? s.ev_k1 : s.ev_front, 0));
         if (int rc = b.enqueue_tail(n_ch, s.segs, tail, s)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
@@ -215,10 +224,13 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
         // the lanes: a narrowband handle's on the work set's stream (the next segment's discriminator overlaps them),
         // a wideband handle's behind its channelizer (see ZbCtx::enqueue_lanes)
-        if (h->wide) { if (int rc = z.enqueue_lanes(n_ch, st)) return rc; }
+        // (split mode, round 6: the wideband lanes too run on the work set's stream -- beside the NEXT segment's
+        //  channelizer, which leaves them zb_split CUs: see snout_rx_create)
+        const bool lanes_front = h->wide && (h->zb_split == 0 || inline_tail);
+        if (lanes_front) { if (int rc = z.enqueue_lanes(n_ch, st)) return rc; }
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
-        if (!h->wide) { if (int rc = z.enqueue_lanes(n_ch, tail)) return rc; }
+        if (!lanes_front) { if (int rc = z.enqueue_lanes(n_ch, tail)) return rc; }
         if (int rc = z.enqueue_tail(n_ch, s.segs, tail, s, !h->wide)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
@@ -369,7 +381,17 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
             chs[b] = c.proto == SNOUT_PROTO_BTLE ? (uint16_t)snout_btle_rf_to_channel((b + 20u) % 40u)
                                                  : (uint16_t)(11u + (b + 8u) % 16u);
         if (c.taps_per_branch != 16) { set_last_error("taps_per_branch must be 16"); goto fail; }
-        rc = h->pfb.init(M, (uint32_t)prop.multiProcessorCount, c.reserved_cus);
+        // Split mode (wideband 802.15.4, SNOUT_ZB_SPLIT = R): the front stream serialises two kernels that underuse the chip in
+        // complementary ways -- the channelizer (VALU-bound, one 16-wave workgroup with 110 KB of LDS per CU) and the lanes
+        // (zb_mm: one serial chain per thread, latency-bound at 1.6 waves per SIMD).  With R CUs left out of the
+        // channelizer's persistent grid, segment i's lanes run on the work set's stream BESIDE segment i + 1's channelizer:
+        // their workgroups (104 registers: they do not fit next to the channelizer's four waves per SIMD) fill exactly the
+        // CUs it leaves free, three workgroups each.
+        if (c.proto == SNOUT_PROTO_ZIGBEE) {
+            if (const char* e = getenv("SNOUT_ZB_SPLIT")) h->zb_split = (uint32_t)atoi(e);
+            if (h->zb_split >= (uint32_t)prop.multiProcessorCount) h->zb_split = 0;
+        }
+        rc = h->pfb.init(M, (uint32_t)prop.multiProcessorCount, std::max(c.reserved_cus, h->zb_split));
         if (rc) goto fail;
         rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments)
                                          : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
@@ -383,7 +405,18 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
                        "Zigbee: 1 or 16)", c.proto, c.n_channels);
         goto fail;
     }
-    if (const char* e = getenv("SNOUT_ONE_TAIL")) h->one_tail = atoi(e) != 0;
+    // Tail streams.  The runtime maps streams onto a handful of hardware queues (four of normal priority): every stream
+    // that exists beyond that -- used or not -- shares a queue with another one, and round 5's three tail streams per handle
+    // put one work set's tail into the FRONT stream's hardware queue (rocprofv3: Queue_Id of stream 7 = that of stream 0):
+    // its kernels then run in queue order in front of the next channelizer launch instead of beside it, and the record
+    // exchange of N > 1 no longer hid under the next step (8-block rehearsal + 41 % instead of + 6 %; profiles/r6_streams.md).
+    // One tail stream, as in rounds 1-4 (BTLE, and wideband 802.15.4: cfg #4 3.47 -> 3.42 ms, cfg #5 6.56 -> 6.02 ms per
+    // step).  Narrowband 802.15.4 keeps three: its lanes (zb_mm) run on the tail stream beside the next segment's
+    // discriminator, and consecutive segments' lanes overlap each other only on separate streams (1e9 samples: 4.05 ms
+    // per step with three, 5.2 with one).
+    if (const char* e = getenv("SNOUT_EXT_LAUNCH")) h->ext_launch = atoi(e) != 0;
+    h->n_tails = (c.proto == SNOUT_PROTO_ZIGBEE && (!h->wide || h->zb_split)) ? 3 : 1;
+    if (const char* e = getenv("SNOUT_TAIL_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 3) h->n_tails = v; }
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
     for (int k = 0; k < 3; k++) {
         if (hipEventCreate(&h->ws_free[k]) != hipSuccess) { rc = SNOUT_EHIP; goto fail; }
@@ -394,7 +427,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
             goto fail;
         }
     }
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < h->n_tails; k++) {
         if (hipStreamCreateWithFlags(&h->tail_streams[k], hipStreamNonBlocking) != hipSuccess) {
             set_last_error("hipStreamCreate failed");
             rc = SNOUT_EHIP;

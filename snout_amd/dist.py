@@ -201,8 +201,24 @@ class AsyncRecordGather:
 
     HDR = 32        # header bytes per rank: count, longest record (host appends), longest record (device appends), launch ticket
     AHEAD = 4       # exchanges a rank may have opened behind the oldest unfinished one
-    _gathers = {}   # process group -> gathers created on it so far (their creation index is part of the ticket)
-    _tickets = {}   # process group -> launches so far
+    # process group -> [the group, gathers created on it so far (their creation index is part of the ticket), launches so far].
+    # The entry HOLDS the group object (keyed by id() alone, a destroyed group's id could be reused by a new one,
+    # whose gathers then started from stale counters); the default group's entry is dropped when torch.distributed has
+    # been shut down or re-initialised since (its WORLD object changed).
+    _groups = {}
+
+    @classmethod
+    def _registry(cls, group, dist):
+        if group is None:
+            world = dist.group.WORLD if dist.is_initialized() else None
+            ent = cls._groups.get(0)
+            if ent is None or ent[0] is not world:
+                ent = cls._groups[0] = [world, 0, 0]
+            return ent
+        ent = cls._groups.get(id(group))
+        if ent is None or ent[0] is not group:
+            ent = cls._groups[id(group)] = [group, 0, 0]
+        return ent
 
     def __init__(self, device=None, group=None, width: int = REC, dedup_tol: Optional[int] = None,
                  cap: int = 0, fake_world: int = 0, prealloc: int = 0):
@@ -237,8 +253,9 @@ class AsyncRecordGather:
         self.cap_from = []              # [(first exchange index, capacity)], ascending
         # exchanges of every gather that shares a process group must be launched in the same order on every rank: each launch
         # takes the group's next ticket, the ticket travels in the header and finish() compares it across the ranks
-        self.gid = AsyncRecordGather._gathers.get(id(group) if group is not None else 0, 0)
-        AsyncRecordGather._gathers[id(group) if group is not None else 0] = self.gid + 1
+        ent = AsyncRecordGather._registry(group, dist)
+        self.gid = ent[1]
+        ent[1] += 1
         self.expect = None              # record counts of the last finished exchange: what the next download is sized for
         self.pool = []                  # finished slots, oldest first: reused once another has finished (views stay valid until then)
         self.cur = None                 # the open exchange (appends go here)
@@ -422,9 +439,9 @@ class AsyncRecordGather:
             raise RuntimeError("two gathers in flight: finish() one first")
         slot = self.closed.pop(0)
         W, cap, B = self.width, slot["cap"], self.blocks
-        gkey = id(self.group) if self.group is not None else 0
-        ticket = AsyncRecordGather._tickets.get(gkey, 0)
-        AsyncRecordGather._tickets[gkey] = ticket + 1
+        ent = AsyncRecordGather._registry(self.group, self.dist)
+        ticket = ent[2]
+        ent[2] += 1
         with self._ctx():
             heads = slot["heads"]
             slot["hsend"][2] = (self.gid << 40) | ticket         # (its own staging word: close()'s copy may still be reading the others)

@@ -52,7 +52,8 @@ class ShardedScan:
         # padded with zeros to the common length (it decodes nothing there): a capture's segments then go to the library as
         # ONE submission instead of three -- each submission costs a lane's whole serial clock recovery however few
         # samples it holds (cfg #5: three 802.15.4 submissions per step cost 3 x ~1.2 ms of zb_mm, profiles/r5_cfg5.md)
-        # (done for every batch size, 1 included, so that what a capture decodes to does not depend on the batch)
+        # (done for every batch size, 1 included, so that what a capture decodes to does not depend on the batch -- but only
+        #  for captures of MORE than one segment: a short capture is one segment of its own length, not a zero-padded 2^24)
         self.pad_to = self.seg_len + self.overlap + self.preroll
         self.stream_priority = int(stream_priority)                   # of the handles' streams (-1: high: the scan's small kernels go first)
         self.depth = max(1, min(3, int(depth)))                       # submissions in flight per handle (the library holds 3)
@@ -107,6 +108,9 @@ class ShardedScan:
             st.wait_event(ready)
         import torch.distributed as tdist
         self._segs = self.my_segments(n_total, group)
+        # a capture that fits one segment is submitted at its own length (padded to seg_len it cost a full
+        # segment of channelizer and lane work, and a frame cut by its end was pushed on through the zeros)
+        pad_to = self.pad_to if n_total > self.pad_to else 0
         world = tdist.get_world_size(group) if tdist.is_initialized() else 1
         rank = tdist.get_rank(group) if tdist.is_initialized() else 0
         # channel-sample index below which segment j's records belong to the segment before it
@@ -115,15 +119,15 @@ class ShardedScan:
         if not self.active():
             self._parts = []
         # submissions: runs of up to `batch` consecutive segments of equal length
-        subs = sdist.group_submissions(self._segs, self.batch, self.pad_to)
+        subs = sdist.group_submissions(self._segs, self.batch, pad_to)
         for k, sub in enumerate(subs):
-            self._jobs.append(dict(segs=[self._segs[i] for i in sub], own=[own_from[i] for i in sub], source=source, sink=sink,
+            self._jobs.append(dict(segs=[self._segs[i] for i in sub], own=[own_from[i] for i in sub], source=source, sink=sink, pad_to=pad_to,
                                    on_first=on_first if k == 0 else None, on_last=on_last if k == len(subs) - 1 else None))
         if not subs and (on_first is not None or on_last is not None):
             # nothing to do for this rank: the exchange still opens and closes -- in its turn, behind the submissions of
             # the capture before (an empty job carries the callbacks; called here they would open the next exchange while
             # the previous one is still being filled)
-            self._jobs.append(dict(segs=[], own=[], source=source, sink=sink, on_first=on_first, on_last=on_last))
+            self._jobs.append(dict(segs=[], own=[], source=source, sink=sink, pad_to=0, on_first=on_first, on_last=on_last))
 
     def active(self) -> bool:
         return self._streams is not None and bool(self._jobs or self._flight)
@@ -158,8 +162,8 @@ class ShardedScan:
                 self._appended[j % H] = None
             with torch.cuda.stream(st):
                 xs = [job["source"](a, b) for a, b in job["segs"]]
-                if self.pad_to:
-                    xs = [x if (b - a) >= self.pad_to else self.zero_pad(x, self.pad_to - (b - a)) for x, (a, b) in zip(xs, job["segs"])]
+                if job["pad_to"]:
+                    xs = [x if (b - a) >= job["pad_to"] else self.zero_pad(x, job["pad_to"] - (b - a)) for x, (a, b) in zip(xs, job["segs"])]
                 if self.batch > 1:
                     # the library drops what a segment finds before its own range (its pre-roll)
                     self.rxs[j % H].submit_batch(xs, [a // self.decim for a, _ in job["segs"]],
