@@ -104,6 +104,7 @@ struct snout_rx {
     BtleCtx btle, btle2, btle3;
     ZbCtx zb2, zb3;           // (second and third Zigbee work set; the first is `zb`)
     hipStream_t tail_streams[3] = {nullptr, nullptr, nullptr};
+    uint32_t zb_gate_us = 150;    // SNOUT_ZB_GATE_US
     uint32_t zb_split = 0;    // wideband 802.15.4: CUs the channelizer's grid leaves to the lanes (0: lanes behind the channelizer)
     bool ext_launch = true;   // SNOUT_EXT_LAUNCH=0 (A/B): events around the front-end kernels as recorded barrier packets
     int n_tails = 1;          // tail streams CREATED (SNOUT_TAIL_STREAMS overrides): work set k's tail runs on stream k % n_tails
@@ -230,7 +231,14 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         if (lanes_front) { if (int rc = z.enqueue_lanes(n_ch, st)) return rc; }
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
-        if (!lanes_front) { if (int rc = z.enqueue_lanes(n_ch, tail)) return rc; }
+        if (!lanes_front) {
+            // held back until the NEXT channelizer launch (as large as this one, if it comes) is resident: all but a few of
+            // its workgroups have started; 150 us if none comes
+            const bool gated = h->wide && h->pfb.count_starts && h->pfb.d_started.p;
+            const uint32_t slack = h->pfb.last_grid > 16u ? 8u : 0u;
+            if (int rc = z.enqueue_lanes(n_ch, tail, gated ? h->pfb.d_started.as<uint32_t>() : nullptr,
+                                         h->pfb.started_total + h->pfb.last_grid - slack, h->zb_gate_us)) return rc;
+        }
         if (int rc = z.enqueue_tail(n_ch, s.segs, tail, s, !h->wide)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
@@ -390,6 +398,8 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
         if (c.proto == SNOUT_PROTO_ZIGBEE) {
             if (const char* e = getenv("SNOUT_ZB_SPLIT")) h->zb_split = (uint32_t)atoi(e);
             if (h->zb_split >= (uint32_t)prop.multiProcessorCount) h->zb_split = 0;
+            if (const char* e = getenv("SNOUT_ZB_GATE_US")) h->zb_gate_us = (uint32_t)atoi(e);
+            h->pfb.count_starts = h->zb_split != 0 && h->zb_gate_us != 0;
         }
         rc = h->pfb.init(M, (uint32_t)prop.multiProcessorCount, std::max(c.reserved_cus, h->zb_split));
         if (rc) goto fail;
