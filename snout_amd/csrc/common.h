@@ -173,7 +173,6 @@ struct PfbMfArgs {
     uint16_t* planes16;
     uint64_t plane_stride;
     PfbZbOut zb;
-    uint32_t* started;      // split mode: every workgroup counts itself in here as it starts (PfbCtx::d_started), else nullptr
 };
 // M = 40; btle: hard bits into the planes, else channel IQ into y
 int pfb_mfma_launch(uint32_t M, bool btle, int fmt, int impl, uint32_t grid, hipStream_t st, const PfbMfArgs& a);   // impl: 0 MFMA FIR, 1 VALU FIR
@@ -189,12 +188,6 @@ struct PfbCtx {
     uint32_t n_cus = 256, reserved_cus = 0;     // the device's compute units; those the grid leaves free (cfg.reserved_cus)
     enum { kKernelSpec = 0, kKernelSpec12, kKernelMfma, kKernelValu };
     int last_kernel = kKernelSpec;   // the kernel the last launch actually ran (profile names)
-    // Split mode (wideband 802.15.4): the workgroups of every launch count themselves in d_started as they start, so that
-    // the lanes of the segment BEFORE can be held back (zb_gate) until the next channelizer launch is resident on its
-    // share of the CUs.  started_total = workgroups launched so far, last_grid = those of the last launch.
-    DevBuf d_started;
-    bool count_starts = false;
-    uint32_t started_total = 0, last_grid = 0;
     uint32_t small_tiles = 0;        // SNOUT_PFB_SMALL40 / SNOUT_PFB_SMALL16: launches with fewer tiles than this use pfb.hip's kernels (several workgroups per CU
                                      // leave room for other streams' kernels; pfb_spec.hip's one 16-wave workgroup per CU does not)
     int impl = 4;                    // SNOUT_PFB_IMPL, M = 40 kernel: 0 valu = pfb.hip, 1 mfma / 2 spec16 = pfb_mfma.hip with its FIR on the matrix / vector pipe, 3 spec12 / 4 spec = pfb_spec.hip with 12 / 16 waves
@@ -250,9 +243,7 @@ struct ZbCtx {
     // d_iq == nullptr: the fused channelizer has already written d and S (see pfb_target)
     int enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipStream_t st, ResultSlot& s,
                       bool time_front, int fmt = 0);
-    // IIR carry-in + zb_mm (behind enqueue_front's part).  gate != nullptr: first a one-wave kernel that waits until *gate has
-    // reached gate_target (mod 2^32) or gate_us microseconds have passed
-    int enqueue_lanes(uint64_t n_channel_samples, hipStream_t st, const uint32_t* gate = nullptr, uint32_t gate_target = 0, uint32_t gate_us = 0);
+    int enqueue_lanes(uint64_t n_channel_samples, hipStream_t st);     // IIR carry-in + zb_mm (behind enqueue_front's part)
     PfbZbTarget pfb_target(uint32_t seg = 0);
     unsigned long long* seam_masks() const;         // per lane: XOR of the two timing loops' last 48 chips before its seam
     int enqueue_tail(uint64_t n, const SegBatch& segs, hipStream_t st, ResultSlot& s, bool time_front);

@@ -83,7 +83,7 @@ int PfbCtx::init(uint32_t M_, uint32_t n_cus_, uint32_t reserved_)
 
 void PfbCtx::destroy()
 {
-    d_proto.release(); d_tw.release(); d_tw5.release(); d_y.release(); d_started.release();
+    d_proto.release(); d_tw.release(); d_tw5.release(); d_y.release();
 }
 
 uint64_t PfbCtx::n_out_for(uint64_t n) const
@@ -140,7 +140,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
         segs.wgs_per_seg = nwg;
         if (zbt) zero_tails(*zbt, (uint64_t)n_tiles * T, count, d_seg, st);
         PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), mode == 0 ? d_y.as<float2>() : nullptr, y_stride,
-                    planes16, plane_stride, zb, nullptr};
+                    planes16, plane_stride, zb};
         last_kernel = use_valu ? kKernelValu : kKernelMfma;
         if (use_valu) return pfb_valu_launch(M, mode, fmt, nwg * count, st, a, d_tw.as<float>(), d_tw5.as<float>());
         return pfb_mfma_launch(40, planes16 != nullptr, fmt, impl == 1 ? 0 : 1, nwg * count, st, a);
@@ -170,17 +170,7 @@ int PfbCtx::run_batch(const void* const* iqs, uint32_t count, uint64_t n, hipStr
     const uint32_t grid = per_seg * count;
     if (zbt) zero_tails(*zbt, (uint64_t)n_tiles * T, count, d_seg, st);
     PfbMfArgs a{segs, n, n_out, n_tiles, tpw, d_proto.as<float>(), mode == 0 ? d_y.as<float2>() : nullptr,
-                y_stride, planes16, plane_stride, zb, nullptr};
-    if (count_starts) {
-        if (!d_started.p) {
-            if (int rc = d_started.ensure(64)) return rc;
-            SNOUT_HIP(hipMemsetAsync(d_started.p, 0, 64, st));
-            started_total = 0;
-        }
-        a.started = d_started.as<uint32_t>();
-        started_total += grid;
-        last_grid = grid;
-    }
+                y_stride, planes16, plane_stride, zb};
     last_kernel = waves == 12 ? kKernelSpec12 : kKernelSpec;
     hipEvent_t e0 = ev_start, e1 = ev_stop;
     ev_start = ev_stop = nullptr;

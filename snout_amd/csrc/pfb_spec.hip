@@ -287,7 +287,6 @@ void pfb_spec(const PfbMfArgs A)
     const uint32_t t_begin = bid * A.tiles_per_wg;
     uint32_t t_end = t_begin + A.tiles_per_wg;
     if (t_end > n_tiles) t_end = n_tiles;
-    if (A.started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(A.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t_begin >= t_end) return;
     // tiles this workgroup computes: its range, plus (BTLE) the tile behind it, whose first four output times complete the
     // range's last symbols, or (802.15.4) the tile before it, whose last output time the first discriminator value needs

@@ -104,8 +104,6 @@ struct snout_rx {
     BtleCtx btle, btle2, btle3;
     ZbCtx zb2, zb3;           // (second and third Zigbee work set; the first is `zb`)
     hipStream_t tail_streams[3] = {nullptr, nullptr, nullptr};
-    uint32_t zb_gate_us = 150;    // SNOUT_ZB_GATE_US
-    uint32_t zb_split = 0;    // wideband 802.15.4: CUs the channelizer's grid leaves to the lanes (0: lanes behind the channelizer)
     bool ext_launch = true;   // SNOUT_EXT_LAUNCH=0 (A/B): events around the front-end kernels as recorded barrier packets
     int n_tails = 1;          // tail streams CREATED (SNOUT_TAIL_STREAMS overrides): work set k's tail runs on stream k % n_tails
     bool sync_call = false;   // inside snout_rx_process*: nothing to overlap, the tail stays on the caller's stream
@@ -225,20 +223,12 @@ static int enqueue_segment(snout_rx* h, ResultSlot& s, hipStream_t st)
         if (int rc = z.enqueue_front(ch_iq, n_ch, ch_stride, st, s, !h->wide, ch_fmt)) return rc;
         // the lanes: a narrowband handle's on the work set's stream (the next segment's discriminator overlaps them),
         // a wideband handle's behind its channelizer (see ZbCtx::enqueue_lanes)
-        // (split mode, round 6: the wideband lanes too run on the work set's stream -- beside the NEXT segment's
-        //  channelizer, which leaves them zb_split CUs: see snout_rx_create)
-        const bool lanes_front = h->wide && (h->zb_split == 0 || inline_tail);
-        if (lanes_front) { if (int rc = z.enqueue_lanes(n_ch, st)) return rc; }
+        // (measured in round 6 and dropped, profiles/r6_split.md: the wideband lanes on the work set's stream beside the NEXT
+        //  segment's channelizer on CUs its grid leaves free -- the chip is busy either way, the step does not move)
+        if (h->wide) { if (int rc = z.enqueue_lanes(n_ch, st)) return rc; }
         SNOUT_HIP(hipEventRecord(s.ev_front, st));
         if (!inline_tail) SNOUT_HIP(hipStreamWaitEvent(tail, s.ev_front, 0));
-        if (!lanes_front) {
-            // held back until the NEXT channelizer launch (as large as this one, if it comes) is resident: all but a few of
-            // its workgroups have started; 150 us if none comes
-            const bool gated = h->wide && h->pfb.count_starts && h->pfb.d_started.p;
-            const uint32_t slack = h->pfb.last_grid > 16u ? 8u : 0u;
-            if (int rc = z.enqueue_lanes(n_ch, tail, gated ? h->pfb.d_started.as<uint32_t>() : nullptr,
-                                         h->pfb.started_total + h->pfb.last_grid - slack, h->zb_gate_us)) return rc;
-        }
+        if (!h->wide) { if (int rc = z.enqueue_lanes(n_ch, tail)) return rc; }
         if (int rc = z.enqueue_tail(n_ch, s.segs, tail, s, !h->wide)) return rc;
         SNOUT_HIP(hipEventRecord(s.ev_compute, tail));
         SNOUT_HIP(hipEventRecord(h->ws_free[s.work_set], tail));
@@ -389,19 +379,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
             chs[b] = c.proto == SNOUT_PROTO_BTLE ? (uint16_t)snout_btle_rf_to_channel((b + 20u) % 40u)
                                                  : (uint16_t)(11u + (b + 8u) % 16u);
         if (c.taps_per_branch != 16) { set_last_error("taps_per_branch must be 16"); goto fail; }
-        // Split mode (wideband 802.15.4, SNOUT_ZB_SPLIT = R): the front stream serialises two kernels that underuse the chip in
-        // complementary ways -- the channelizer (VALU-bound, one 16-wave workgroup with 110 KB of LDS per CU) and the lanes
-        // (zb_mm: one serial chain per thread, latency-bound at 1.6 waves per SIMD).  With R CUs left out of the
-        // channelizer's persistent grid, segment i's lanes run on the work set's stream BESIDE segment i + 1's channelizer:
-        // their workgroups (104 registers: they do not fit next to the channelizer's four waves per SIMD) fill exactly the
-        // CUs it leaves free, three workgroups each.
-        if (c.proto == SNOUT_PROTO_ZIGBEE) {
-            if (const char* e = getenv("SNOUT_ZB_SPLIT")) h->zb_split = (uint32_t)atoi(e);
-            if (h->zb_split >= (uint32_t)prop.multiProcessorCount) h->zb_split = 0;
-            if (const char* e = getenv("SNOUT_ZB_GATE_US")) h->zb_gate_us = (uint32_t)atoi(e);
-            h->pfb.count_starts = h->zb_split != 0 && h->zb_gate_us != 0;
-        }
-        rc = h->pfb.init(M, (uint32_t)prop.multiProcessorCount, std::max(c.reserved_cus, h->zb_split));
+        rc = h->pfb.init(M, (uint32_t)prop.multiProcessorCount, c.reserved_cus);
         if (rc) goto fail;
         rc = c.proto == SNOUT_PROTO_BTLE ? h->btle.init(M, chs, c.access_addr, c.crc_init, c.max_hits, c.batch_segments)
                                          : h->zb.init(M, chs, c.chip_threshold, c.zb_core, c.zb_warmup, c.batch_segments);
@@ -425,7 +403,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     // discriminator, and consecutive segments' lanes overlap each other only on separate streams (1e9 samples: 4.05 ms
     // per step with three, 5.2 with one).
     if (const char* e = getenv("SNOUT_EXT_LAUNCH")) h->ext_launch = atoi(e) != 0;
-    h->n_tails = (c.proto == SNOUT_PROTO_ZIGBEE && (!h->wide || h->zb_split)) ? 3 : 1;
+    h->n_tails = (c.proto == SNOUT_PROTO_ZIGBEE && !h->wide) ? 3 : 1;
     if (const char* e = getenv("SNOUT_TAIL_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 3) h->n_tails = v; }
     for (auto& s : h->slots) { rc = s.init(); if (rc) goto fail; }
     for (int k = 0; k < 3; k++) {

@@ -1776,23 +1776,9 @@ int ZbCtx::enqueue_front(const void* d_iq, uint64_t n, uint64_t iq_stride, hipSt
 // measured too (zb_mm cut to 96 registers so that it fits next to the channelizer's four waves per SIMD): the
 // channelizer's 16 fast_atan2f per output time keep the vector pipe as busy as the lanes need it, it took 3.5 ms instead
 // of 1.8 and the step did not move (profiles/r5_repair.md).  No host sync.
-// Split mode: one wave that returns when the channelizer launch behind this segment's has put its workgroups on the CUs
-// (its start counter has reached `target`, compared modulo 2^32), or after `wait_us` microseconds -- there may be no such
-// launch.  Launched in front of the lanes, whose workgroups would otherwise be dispatched a few microseconds BEFORE the next
-// channelizer's and take CUs all over the chip away from it for their whole run (profiles/r6_split.md).
-__global__ __launch_bounds__(64) void zb_gate(const uint32_t* __restrict__ started, uint32_t target, uint32_t wait_us)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-    while ((int32_t)(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 100ull * wait_us) break;
-        __builtin_amdgcn_s_sleep(32);
-    }
-}
-
-int ZbCtx::enqueue_lanes(uint64_t n, hipStream_t st, const uint32_t* gate, uint32_t gate_target, uint32_t gate_us)
+int ZbCtx::enqueue_lanes(uint64_t n, hipStream_t st)
 {
     if (n < 9u) return 0;
-    if (gate) hipLaunchKernelGGL(zb_gate, dim3(1), dim3(64), 0, st, gate, gate_target, gate_us);
     hipLaunchKernelGGL(zb_iir_fold, dim3(cdiv(total_lanes, 256)), dim3(256), 0, st, d_S.as<double>(), nsb,
                        lanes_per_slot, total_lanes, core, warmup, d64, d_Lblk.as<double>());
     hipLaunchKernelGGL(zb_mm<false>, dim3(cdiv(n_waves, kMmWaves)), dim3(kMmWaves * 64), 0, st, d_d.as<float>(), d_stride, n, nt, lanes_per_slot,
