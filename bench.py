@@ -612,7 +612,7 @@ def read_peak(x, device):
 def traffic_from_profiles(workload: str, kernel: str, n: int):
     """PMC-derived HBM bytes per launch of the same kernel / workload, from the committed profile
     pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected); None when there is none."""
-    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
