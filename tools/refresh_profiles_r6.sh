@@ -41,8 +41,11 @@ run b "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CO
 run c "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"
 # per-wave cycle stamps of the headline channelizer (a -DSNOUT_MF_STAMPS build of pfb_spec.hip: tools/pfb_variants.sh spstamps:"-DSNOUT_MF_STAMPS")
 [ -f $R/build/variants/libsnout_rx_spstamps.so ] && SNOUT_RX_LIB=$R/build/variants/libsnout_rx_spstamps.so timeout 600 python3 $R/tools/mf_stamps.py > $O/spec40_stamps.txt 2>&1
-# the per-dispatch traces are large and not needed once the stats exist (gpurun copies back <= 64 MiB)
+# the per-dispatch traces are large and not needed once the stats exist (gpurun copies back <= 64 MiB); of the counter
+# passes only this library's kernels are kept (the captures' generation is thousands of torch dispatches)
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+for f in $(find $O -name "*counter_collection.csv"); do (head -1 $f; grep "snout::" $f) > $f.tmp; mv $f.tmp $f; done
+du -sh $O
 # the unprofiled line the round is judged on, for comparison with the traced runs
 ( time timeout 1500 $B > $O/bench_plain.log 2> $O/bench_plain.err ) 2> $O/bench_plain.time
-tail -n 1 $O/bench.log | cut -c1-300; tail -n 1 $O/bench_plain.log | cut -c1-300; cat $O/bench_plain.time; cat $O/*/steady.txt | grep -c NOT_STEADY
+tail -n 1 $O/bench.log | cut -c1-300; tail -n 1 $O/bench_plain.log | cut -c1-300; cat $O/bench_plain.time; echo "traces that are not the steady state: $(cat $O/*/steady.txt | grep -c NOT_STEADY)"
