@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-/* 3: the 802.15.4 frame repair (snout_pkt.flags SNOUT_PKT_ZB_REPAIRED) and ONE default lane shape, 6144 / 1024, whatever the size
+/* 4: the default 802.15.4 lane shape is 6144 / 3072 (warm-up 1024 before): half the frames lost against the one sequential
+ *    receiver for + 1 % step time on the wideband workloads (profiles/r6_fidelity.md); a client built against 3 fails the
+ *    handshake instead of decoding another frame set
+ * 3: the 802.15.4 frame repair (snout_pkt.flags SNOUT_PKT_ZB_REPAIRED) and ONE default lane shape (then 6144 / 1024), whatever the size
  *    of a call (snout_zigbee_lane_shape ignores its argument): the records of a capture no longer depend on how it is cut
  *    into submissions, and the default decode loses <= 1 % of the one sequential receiver's frames on dense traffic and
  *    finds 1-2 % that it misses (measured per run: bench.py frames_lost_vs_sequential)
@@ -38,7 +41,7 @@ extern "C" {
  *    snout_pkt.flags SNOUT_PKT_ZB_SEAM_DISAGREED, snout_zigbee_lane_shape (the default 802.15.4 lane shape depends on the
  *    size of the call), the bench aid moved to snout_bench.h -- a client built against version 1 fails the handshake in
  *    snout_rx_create instead of decoding a different frame set or missing a symbol */
-#define SNOUT_ABI_VERSION 3u
+#define SNOUT_ABI_VERSION 4u
 
 /* protocols (snout/core/protocols/__init__.py:2-27 names them BTLE / ZIGBEE) */
 #define SNOUT_PROTO_BTLE   0u
@@ -95,7 +98,7 @@ typedef struct snout_rx_cfg {
     uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 (with zb_warmup != 0) -> 2048 */
     uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 (with zb_core != 0) -> 512;
                                  multiples of 64, warm-up < core; the timing loop needs >= 256.
-                                 BOTH 0 (the default): core 6144 / warm-up 1024 (snout_zigbee_lane_shape),
+                                 BOTH 0 (the default): core 6144 / warm-up 3072 (snout_zigbee_lane_shape),
                                  the same for every call of every handle.  The decoded frame set is a function
                                  of the shape and of where the calls cut the capture;
                                  zb_core >= the call's channel samples is the reference's one sequential loop  */

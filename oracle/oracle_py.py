@@ -210,8 +210,8 @@ def zb_discrim(iq: np.ndarray) -> np.ndarray:
 
 def zb_auto_shape(total_channel_samples: int = 0):
     """The product's default lane shape (cfg.zb_core = cfg.zb_warmup = 0; snout_zigbee_lane_shape): one shape whatever the
-    size of the call (ABI 3)."""
-    return (6144, 1024)
+    size of the call (ABI 3; warm-up 3072 since ABI 4)."""
+    return (6144, 3072)
 
 
 def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 0,

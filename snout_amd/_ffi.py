@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNOUT_RX_LIB") or os.path.join(_HERE, "lib", "libsnout_rx.so")   # override: A/B builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PROTO_BTLE, PROTO_ZIGBEE = 0, 1
 CFG_KEEP_CHANNEL_IQ, CFG_RECORDS_ON_DEVICE = 1, 2
 STAGE_BTLE_BITS, STAGE_CHAN_IQ, STAGE_ZB_DISCRIM, STAGE_ZB_DCREMOVED, STAGE_ZB_CHIPS = range(5)

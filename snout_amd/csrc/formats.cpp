@@ -108,12 +108,15 @@ int snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap)
 void snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup)
 {
     // One shape for every call since ABI 3 (round 5): what a capture decodes to must not depend on how it is cut into
-    // submissions.  6144 / 1024 with the frame repair loses 0.4 % of the one sequential loop's frames on cfg #4's dense
-    // traffic and reports 0.6 % that it misses (profiles/r5_lane_fidelity.md); longer cores leave the GPU fewer lanes than
-    // it has SIMDs (8192 / 1024: the same fidelity within the error, + 10 % step time), shorter ones hand over more often.
+    // submissions.  ABI 4 (round 6): warm-up 3072 instead of 1024.  On 6 998 distinct frames of cfg #4 / #5's dense traffic
+    // (profiles/r6_fidelity.md, GPU, against one sequential lane per channel): 6144 / 1024 loses 0.64 % of the sequential
+    // loop's frames and reports 1.10 % that it misses, 6144 / 3072 0.30 % + 0.74 % for + 1 % of cfg #4's step time (a fresh
+    // loop's phase agrees with the sequential loop's at 60 % of the seams after 1 024 samples, at ~85 % after 3 072);
+    // longer cores leave the GPU fewer lanes than it has SIMDs (8192 / 4096: 0.43 % + 0.46 %, + 12 %; 16384 / 8192:
+    // 0.19 % + 0.23 %, + 35 %), shorter ones hand over more often.
     (void)channel_samples;
     if (core) *core = 6144u;
-    if (warmup) *warmup = 1024u;
+    if (warmup) *warmup = 3072u;
 }
 
 double snout_zigbee_center_hz(uint32_t channel)

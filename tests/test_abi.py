@@ -129,11 +129,11 @@ def test_lane_shape_rule_is_the_oracles():
     for total in (0, 1, 1 << 20, (1 << 29) - 1, 1 << 29, (1 << 29) + 1, 10 ** 9, 1 << 40):
         c, w = C.c_uint32(0), C.c_uint32(0)
         lib.snout_zigbee_lane_shape(C.c_uint64(total), C.byref(c), C.byref(w))
-        assert (c.value, w.value) == oracle_py.zb_auto_shape(total) == (6144, 1024), total
+        assert (c.value, w.value) == oracle_py.zb_auto_shape(total) == (6144, 3072), total
 
 
 def test_abi_version_and_record_flags_of_the_header():
-    """ABI 3 (round 5): one default 802.15.4 lane shape and the frame repair's record flag.  The header, the binding and the
+    """ABI 3 (round 5): one default 802.15.4 lane shape and the frame repair's record flag; ABI 4 (round 6): that shape's warm-up.  The header, the binding and the
     library agree on the version; the two 802.15.4 record flags are distinct bits that do not collide with the BTLE
     TxAdd / RxAdd bits."""
     import os
@@ -141,7 +141,7 @@ def test_abi_version_and_record_flags_of_the_header():
     from snout_amd import _ffi
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "snout_rx.h")).read()
     ver = int(re.search(r"#define SNOUT_ABI_VERSION (\d+)u", hdr).group(1))
-    assert ver == _ffi.ABI_VERSION == _ffi.load().snout_abi_version() == 3
+    assert ver == _ffi.ABI_VERSION == _ffi.load().snout_abi_version() == 4
     seam = int(re.search(r"#define SNOUT_PKT_ZB_SEAM_DISAGREED (0x[0-9a-fA-F]+)u", hdr).group(1), 16)
     rep = int(re.search(r"#define SNOUT_PKT_ZB_REPAIRED (0x[0-9a-fA-F]+)u", hdr).group(1), 16)
     assert (seam, rep) == (4, 8) and not (seam | rep) & 3

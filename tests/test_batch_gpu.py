@@ -233,7 +233,7 @@ def test_records_stay_on_the_device():
 
 
 def test_the_default_lane_shape_is_the_same_for_a_batch_and_its_segments(oracle):
-    """cfg.zb_core = cfg.zb_warmup = 0: ONE default lane shape (6144 / 1024, snout_zigbee_lane_shape) whatever a submission
+    """cfg.zb_core = cfg.zb_warmup = 0: ONE default lane shape (6144 / 3072, snout_zigbee_lane_shape) whatever a submission
     carries (round 4 chose the shape by channels x samples x segments of the submission, so the last, shorter
     batch of a capture -- or another world size -- decoded another frame set).  33 segments of 2^23 input samples in one
     batch decode what each decodes alone, which is what the oracle decodes with the default shape; an explicit zb_core
@@ -252,7 +252,7 @@ def test_the_default_lane_shape_is_the_same_for_a_batch_and_its_segments(oracle)
         want_short = oracle.wideband_segment(x[:n_in], 1, core=2048, warmup=512)
     finally:
         oracle.set_threads(1)
-    assert len(want) > 300 and oracle.zb_auto_shape() == (6144, 1024)
+    assert len(want) > 300 and oracle.zb_auto_shape() == (6144, 3072)
     with SnoutRx(proto=1, n_channels=16, batch_segments=count) as rx:
         rx.submit_batch([cap] * count, firsts)
         got = rx.collect()
