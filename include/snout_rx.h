@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* 4: the default 802.15.4 lane shape is 6144 / 3072 (warm-up 1024 before): half the frames lost against the one sequential
- *    receiver for + 1 % step time on the wideband workloads (profiles/r6_fidelity.md); a client built against 3 fails the
+ *    receiver for + 3-4 % step time on the wideband 802.15.4 workloads (profiles/r6_fidelity.md); a client built against 3 fails the
  *    handshake instead of decoding another frame set
  * 3: the 802.15.4 frame repair (snout_pkt.flags SNOUT_PKT_ZB_REPAIRED) and ONE default lane shape (then 6144 / 1024), whatever the size
  *    of a call (snout_zigbee_lane_shape ignores its argument): the records of a capture no longer depend on how it is cut

@@ -110,7 +110,7 @@ void snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t*
     // One shape for every call since ABI 3 (round 5): what a capture decodes to must not depend on how it is cut into
     // submissions.  ABI 4 (round 6): warm-up 3072 instead of 1024.  On 6 998 distinct frames of cfg #4 / #5's dense traffic
     // (profiles/r6_fidelity.md, GPU, against one sequential lane per channel): 6144 / 1024 loses 0.64 % of the sequential
-    // loop's frames and reports 1.10 % that it misses, 6144 / 3072 0.30 % + 0.74 % for + 1 % of cfg #4's step time (a fresh
+    // loop's frames and reports 1.10 % that it misses, 6144 / 3072 0.30 % + 0.74 % for + 3-4 % of cfg #4's and cfg #5's step time (a fresh
     // loop's phase agrees with the sequential loop's at 60 % of the seams after 1 024 samples, at ~85 % after 3 072);
     // longer cores leave the GPU fewer lanes than it has SIMDs (8192 / 4096: 0.43 % + 0.46 %, + 12 %; 16384 / 8192:
     // 0.19 % + 0.23 %, + 35 %), shorter ones hand over more often.
