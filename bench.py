@@ -391,7 +391,7 @@ def lost_vs_sequential(x_dev, workload: str, n_sample: int, device, fmt: int, sh
     res = {"samples": int(n_sample), "sequential_frames": len(ko), "distinct_sequential_frames": len({(c, b) for c, b, _ in ko}),
            "default_frames": d["frames"], "lost": d["lost"], "extra": d["extra"],
            "frac_lost": d["frac_lost"], "frac_extra": d["frac_extra"], "frac_lost_plus_extra": d["frac_lost_plus_extra"],
-           "repaired": d["repaired"], "lane_shape": "6144 / 3072 (default) + frame repair",
+           "repaired": d["repaired"], "lane_shape": "%s (default) + frame repair" % ("6144 / 3072" if n_ch > 1 else "6144 / 1024"),
            "sequential": "zb_core >= the prefix: one lane per channel on the GPU (== the oracle's, == Zigbee_rx/top_block.py:67,69)"}
     if shapes:
         res["fidelity_modes"] = {"%d / %d" % (c, w): against(c, w) for c, w in shapes}
@@ -586,7 +586,7 @@ def run_workload(name: str, n: int, steps: int, warmup: int, device, rank: int, 
                 torch.cuda.synchronize(device)
                 fl["fidelity_modes"]["%d / %d" % (core, warm)]["ms_per_step"] = (time.perf_counter() - t1) / 10 * 1e3
         if shapes:
-            fl["fidelity_modes"]["6144 / 3072 (default)"] = {"lost": fl["lost"], "extra": fl["extra"], "frac_lost": fl["frac_lost"],
+            fl["fidelity_modes"]["%s (default)" % ("6144 / 3072" if n_ch > 1 else "6144 / 1024")] = {"lost": fl["lost"], "extra": fl["extra"], "frac_lost": fl["frac_lost"],
                                                              "frac_extra": fl["frac_extra"], "ms_per_step": res["ms_per_step"]}
         res["frames_lost_vs_sequential"] = fl
     if keep_capture:

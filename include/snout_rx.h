@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-/* 4: the default 802.15.4 lane shape is 6144 / 3072 (warm-up 1024 before): half the frames lost against the one sequential
+/* 4: the default 802.15.4 lane shape of a WIDEBAND handle is 6144 / 3072 (warm-up 1024 before, and still for a narrowband
+ *    handle; snout_zigbee_lane_shape takes the handle's n_channels): half the frames lost against the one sequential
  *    receiver for + 3-4 % step time on the wideband 802.15.4 workloads (profiles/r6_fidelity.md); a client built against 3 fails the
  *    handshake instead of decoding another frame set
  * 3: the 802.15.4 frame repair (snout_pkt.flags SNOUT_PKT_ZB_REPAIRED) and ONE default lane shape (then 6144 / 1024), whatever the size
@@ -98,7 +99,8 @@ typedef struct snout_rx_cfg {
     uint32_t zb_core;         /* Zigbee lane core length in channel samples; 0 (with zb_warmup != 0) -> 2048 */
     uint32_t zb_warmup;       /* Zigbee lane warm-up before its core, channel samples; 0 (with zb_core != 0) -> 512;
                                  multiples of 64, warm-up < core; the timing loop needs >= 256.
-                                 BOTH 0 (the default): core 6144 / warm-up 3072 (snout_zigbee_lane_shape),
+                                 BOTH 0 (the default): core 6144 / warm-up 3072 for a wideband handle, 6144 / 1024 for a
+                                 narrowband one (snout_zigbee_lane_shape(n_channels)),
                                  the same for every call of every handle.  The decoded frame set is a function
                                  of the shape and of where the calls cut the capture;
                                  zb_core >= the call's channel samples is the reference's one sequential loop  */
@@ -260,7 +262,7 @@ double   snout_zigbee_center_hz(uint32_t channel);   /* 1e6*(2400+5*(ch-10)), to
 /* The 802.15.4 lane shape a handle with cfg.zb_core = cfg.zb_warmup = 0 uses: the clock recovery (clock_recovery_mm_ff,
  * top_block.py:69) runs in lanes of `core` samples that start `warmup` samples early.  Since ABI 3 one shape for every call
  * (`channel_samples` is ignored); results are a function of the shape, so a checker has to run the same one. */
-void     snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup);
+void     snout_zigbee_lane_shape(uint64_t n_channels, uint32_t* core, uint32_t* warmup);
 double   snout_btle_center_hz(uint32_t channel);     /* 37->2402, 38->2426, 39->2480, data channels */
 int32_t  snout_btle_rf_to_channel(uint32_t rf_index);/* RF k (2402+2k MHz) -> BLE channel index    */
 

@@ -208,19 +208,19 @@ def zb_discrim(iq: np.ndarray) -> np.ndarray:
     return d[:n]
 
 
-def zb_auto_shape(total_channel_samples: int = 0):
-    """The product's default lane shape (cfg.zb_core = cfg.zb_warmup = 0; snout_zigbee_lane_shape): one shape whatever the
-    size of the call (ABI 3; warm-up 3072 since ABI 4)."""
-    return (6144, 3072)
+def zb_auto_shape(n_channels: int = 16):
+    """The product's default lane shape (cfg.zb_core = cfg.zb_warmup = 0; snout_zigbee_lane_shape(n_channels)): one shape per
+    kind of handle whatever the size of a call (ABI 3); ABI 4: warm-up 3072 for wideband handles, 1024 for narrowband ones."""
+    return (6144, 1024) if n_channels <= 1 else (6144, 3072)
 
 
 def zigbee_segment(iq: np.ndarray, channel: int = 11, threshold: int = 10, core: int = 0,
                    warmup: int = 0, first_sample_index: int = 0, cap: int = 0) -> np.ndarray:
-    """core = warmup = 0: the product's default (by the size of the call); core alone: warm-up 512."""
+    """core = warmup = 0: the product's default for a narrowband handle; core alone: warm-up 512."""
     a = _f32(iq)
     n = a.size // 2
     if core == 0 and warmup == 0:
-        core, warmup = zb_auto_shape(n)
+        core, warmup = zb_auto_shape(1)
     core, warmup = core or 2048, warmup or 512
     cap = cap or max(64, n // 512)
     out = np.zeros(cap, dtype=PKT_DTYPE)
@@ -286,7 +286,7 @@ def wideband_segment(iq: np.ndarray, proto: int, first_sample_index: int = 0, aa
     a = _f32(iq)
     n = a.size // 2
     if proto == 1 and core == 0 and warmup == 0:        # the product's default
-        core, warmup = zb_auto_shape()
+        core, warmup = zb_auto_shape(16)
     core, warmup = core or 2048, warmup or 512
     cap = cap or max(256, n // 128)
     out = np.zeros(cap, dtype=PKT_DTYPE)

@@ -197,9 +197,9 @@ def zigbee():
 @_scan_options
 @click.option("--udp", is_flag=True, help="send RFtap datagrams to 127.0.0.1:52002 (scapy-radio)")
 @click.option("--lane-core", type=int, default=0,
-              help="clock-recovery lane length in channel samples (multiple of 64; 0: the default shape, 6144 with warm-up 3072). The "
+              help="clock-recovery lane length in channel samples (multiple of 64; 0: the default shape, 6144 with warm-up 3072 for --wideband scans, 1024 for single-channel ones). The "
                    "reference's receiver is ONE sequential loop: a lane at least as long as the capture is that loop (DESIGN.md 6-3)")
-@click.option("--lane-warmup", type=int, default=0, help="samples a lane's timing loop starts before its core (multiple of 64; 0 with --lane-core 0: 3072, the default shape; "
+@click.option("--lane-warmup", type=int, default=0, help="samples a lane's timing loop starts before its core (multiple of 64; 0 with --lane-core 0: the default shape; "
                    "0 with a --lane-core: 512)")
 def zigbee_scan(channels, active, packets, timeout, wideband, sharded, segment, batch, filename, iq, fmt, synthetic,
                 seconds, udp, lane_core, lane_warmup):

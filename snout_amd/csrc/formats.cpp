@@ -105,7 +105,7 @@ int snout_rftap_encap(const snout_pkt* p, uint8_t* dst, size_t cap)
     return (int)total;
 }
 
-void snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t* warmup)
+void snout_zigbee_lane_shape(uint64_t n_channels, uint32_t* core, uint32_t* warmup)
 {
     // One shape for every call since ABI 3 (round 5): what a capture decodes to must not depend on how it is cut into
     // submissions.  ABI 4 (round 6): warm-up 3072 instead of 1024.  On 6 998 distinct frames of cfg #4 / #5's dense traffic
@@ -114,9 +114,13 @@ void snout_zigbee_lane_shape(uint64_t channel_samples, uint32_t* core, uint32_t*
     // loop's phase agrees with the sequential loop's at 60 % of the seams after 1 024 samples, at ~85 % after 3 072);
     // longer cores leave the GPU fewer lanes than it has SIMDs (8192 / 4096: 0.43 % + 0.46 %, + 12 %; 16384 / 8192:
     // 0.19 % + 0.23 %, + 35 %), shorter ones hand over more often.
-    (void)channel_samples;
+    // That is the WIDEBAND handles' shape (16 adjacent channels out of one channelizer: a transmitting neighbour 2 MHz
+    // either side drags a young loop).  A narrowband handle (n_channels <= 1: one channel as an SDR's own filter delivers
+    // it) keeps ABI 3's 6144 / 1024: its traffic has no such neighbours (bench line, 544 distinct frames: 1 lost + 0 extra
+    // with 1024, 0 + 0 with 3072), and its lanes -- 163 000 per 1e9 samples -- are throughput-bound, so the longer warm-up
+    // would cost it 9 % (4.29 -> 4.67 ms per 1e9 samples).  Either way ONE shape per handle, whatever the size of a call.
     if (core) *core = 6144u;
-    if (warmup) *warmup = 3072u;
+    if (warmup) *warmup = n_channels <= 1u ? 1024u : 3072u;
 }
 
 double snout_zigbee_center_hz(uint32_t channel)

@@ -338,7 +338,7 @@ int snout_rx_create(const snout_rx_cfg* cfg, snout_rx** out)
     if (c.crc_init == 0) c.crc_init = 0x555555u;
     if (c.chip_threshold == 0) c.chip_threshold = 10;
     if (c.taps_per_branch == 0) c.taps_per_branch = 16;
-    if (c.zb_core == 0 && c.zb_warmup == 0) snout_zigbee_lane_shape(0, &c.zb_core, &c.zb_warmup);   // the default shape, fixed per handle
+    if (c.zb_core == 0 && c.zb_warmup == 0) snout_zigbee_lane_shape(c.n_channels, &c.zb_core, &c.zb_warmup);   // the default shape, fixed per handle (by its kind: n_channels is defaulted below, 0 = narrowband)
     if (c.zb_core == 0) c.zb_core = 2048;
     if (c.zb_warmup == 0) c.zb_warmup = 512;
     if (c.n_channels == 0) c.n_channels = 1;

@@ -126,10 +126,13 @@ def test_lane_shape_rule_is_the_oracles():
     from snout_amd import _ffi
     from oracle import oracle_py
     lib = _ffi.load()
-    for total in (0, 1, 1 << 20, (1 << 29) - 1, 1 << 29, (1 << 29) + 1, 10 ** 9, 1 << 40):
-        c, w = C.c_uint32(0), C.c_uint32(0)
-        lib.snout_zigbee_lane_shape(C.c_uint64(total), C.byref(c), C.byref(w))
-        assert (c.value, w.value) == oracle_py.zb_auto_shape(total) == (6144, 3072), total
+    c, w = C.c_uint32(0), C.c_uint32(0)
+    for total in (16, 2, 1 << 20, 10 ** 9, 1 << 40):
+        lib.snout_zigbee_lane_shape(C.c_uint64(total), C.byref(c), C.byref(w))          # (any n_channels > 1 is a wideband handle)
+        assert (c.value, w.value) == oracle_py.zb_auto_shape(max(2, total)) == (6144, 3072), total
+    for nch in (0, 1):                                  # a narrowband handle keeps ABI 3's warm-up
+        lib.snout_zigbee_lane_shape(C.c_uint64(nch), C.byref(c), C.byref(w))
+        assert (c.value, w.value) == oracle_py.zb_auto_shape(nch) == (6144, 1024)
 
 
 def test_abi_version_and_record_flags_of_the_header():

@@ -252,7 +252,7 @@ def test_the_default_lane_shape_is_the_same_for_a_batch_and_its_segments(oracle)
         want_short = oracle.wideband_segment(x[:n_in], 1, core=2048, warmup=512)
     finally:
         oracle.set_threads(1)
-    assert len(want) > 300 and oracle.zb_auto_shape() == (6144, 3072)
+    assert len(want) > 300 and oracle.zb_auto_shape(16) == (6144, 3072)
     with SnoutRx(proto=1, n_channels=16, batch_segments=count) as rx:
         rx.submit_batch([cap] * count, firsts)
         got = rx.collect()
