@@ -43,7 +43,7 @@ def main(budget_s):
         elif kind == "zigbee":
             n = int(rng.integers(9, 1 << 19))
             core = int(rng.choice([1024, 2048, 4096, 6144, 8192, 16384]))
-            warm = int(rng.choice([w for w in (256, 512, 1024, 2048) if w < core]))
+            warm = int(rng.choice([w for w in (256, 512, 1024, 2048, 3072, 4096) if w < core]))
             # (heavy noise now and then: frames that the lanes' sinks give up behind a seam, i.e. frame repairs)
             x, _ = synth.zigbee_capture(n, seed=seed, mean_gap=float(rng.choice([400.0, 4000.0, 20000.0])),
                                         cfo_max_hz=float(rng.choice([0.0, 40e3, 100e3])), sigma=float(rng.choice([0.02, 0.05, 0.3, 0.5])))
