@@ -419,3 +419,43 @@ def test_too_wide_record_on_one_rank_raises_on_every_rank_gloo_world2():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == {0: "ValueError", 1: "ValueError"}
+
+
+def test_the_gathers_registry_holds_its_groups():
+    """launch tickets and creation indices are kept per process GROUP OBJECT, not per id(): a new group that
+    happens to get a destroyed group's id starts from zero, and the default group's counters restart when
+    torch.distributed has been re-initialised."""
+    from snout_amd.dist import AsyncRecordGather
+
+    class FakeDist:
+        class group:
+            WORLD = None
+
+        @staticmethod
+        def is_initialized():
+            return FakeDist.group.WORLD is not None
+
+    class G:
+        pass
+
+    saved = dict(AsyncRecordGather._groups)
+    try:
+        AsyncRecordGather._groups.clear()
+        g1 = G()
+        e1 = AsyncRecordGather._registry(g1, FakeDist)
+        e1[1] += 2
+        e1[2] += 5
+        assert AsyncRecordGather._registry(g1, FakeDist) is e1 and e1[0] is g1          # the entry keeps the group alive
+        g2 = G()
+        AsyncRecordGather._groups[id(g2)] = [g1, 7, 7]                                   # a stale entry under g2's id
+        e2 = AsyncRecordGather._registry(g2, FakeDist)
+        assert e2[0] is g2 and e2[1:] == [0, 0]                                          # not the stale counters
+        FakeDist.group.WORLD = object()
+        d1 = AsyncRecordGather._registry(None, FakeDist)
+        d1[2] += 3
+        assert AsyncRecordGather._registry(None, FakeDist) is d1
+        FakeDist.group.WORLD = object()                                                  # destroy_process_group + init again
+        assert AsyncRecordGather._registry(None, FakeDist)[1:] == [0, 0]
+    finally:
+        AsyncRecordGather._groups.clear()
+        AsyncRecordGather._groups.update(saved)

@@ -238,6 +238,37 @@ def test_sharded_scan_equals_one_shot(oracle):
     assert sum(s in set(good) for s in sent) >= sum(s in one for s in sent) - 1 >= 0.9 * len(sent)
 
 
+def test_a_capture_that_fits_one_segment_is_not_padded(oracle):
+    """a sharded scan pads a short segment to the common length only when the capture has MORE than one segment
+    (so that a rank's segments are one batch).  A capture that fits one segment goes to the library at its own length: the
+    same records as one process() call on it, also with a frame cut by the capture's end (padded with zeros, that frame
+    was pushed on through the zeros), and no full segment's worth of channelizer and lane work for a few samples."""
+    import torch
+    from snout_amd.rx import SnoutRx
+    from snout_amd.sharded import ShardedScan
+    x, truth = synth.wideband_capture(1, 16 * 60000, seed=21, bins=[1, 6, 9, 14], mean_gap=6000.0)
+    x = x[:16 * 52000 + 3200]                                       # the cut falls into frames
+    t = torch.from_numpy(np.ascontiguousarray(x).view(np.float32)).cuda()
+    for batch in (1, 4):
+        sc = ShardedScan(proto=1, n_channels=16, seg_len=1 << 24, batch=batch)
+        assert len(x) <= sc.pad_to
+        sc.start(len(x), lambda a, b: t[2 * a:2 * b])
+        assert [j["pad_to"] for j in sc._jobs] == [0] and sc._jobs[0]["segs"] == [(0, len(x))]
+        while sc.active():
+            sc.step()
+        got = sc.finish(sc._parts)
+        sc.close()
+        want = oracle.wideband_segment(x, 1)
+        assert len(got) == len(want) > 20 and got.tobytes() == want.tobytes()
+    # a capture of several segments still has ONE length per submission (its last segment padded)
+    sc = ShardedScan(proto=1, n_channels=16, seg_len=16 * 16384, batch=4)
+    sc.start(len(x), lambda a, b: t[2 * a:2 * b])
+    assert all(j["pad_to"] == sc.pad_to for j in sc._jobs) and len(sc._segs) > 2
+    while sc.active():
+        sc.step()
+    sc.close()
+
+
 def test_lanes_against_one_lane_on_a_noisy_wideband_capture():
     """The residual of the lane decomposition where it is largest (DESIGN.md deviation 3): a 16-channel
     capture with noise added on top of the channelizer's leakage, many frames with marginal chips.  One lane
