@@ -27,6 +27,14 @@ processes its own copy of it, records gathered per step).
 A "step" is one pass of the whole receive path over the resident capture, packet records landed in
 host memory (rank 0's for N > 1).  Prints ONE JSON line (rank 0).  Kernel durations are HIP-event
 pairs recorded on the kernel's own stream during the timed steps.
+
+Captures (round 6): every capture cycles through TILES = 32 independently seeded, noise-free tiles of the workload's
+traffic (narrowband tiles from snout_amd.synth on the host, wideband ones composed on the device by the same upsampler:
+wideband_tile_dev) plus independent AWGN on every sample -- a statistic over a capture counts thousands of DISTINCT packets.
+Checks outside the timed region: `parity_in_run` (the HIP path's records == the CPU oracle's, every field and byte: whole
+captures at N = 1; cfg #5 at every N -- every rank's oracle records gathered to rank 0), `frames_lost_vs_sequential` with
+`fidelity_modes` for the 802.15.4 lines (the default lanes + frame repair against ONE sequential lane per channel, the
+reference's receiver).  `frac` prices the dominant kernel's event duration, `step_frac` the whole step.
 """
 from __future__ import annotations
 
