@@ -415,13 +415,23 @@ def _pkt_dtype():
 
 
 def reserved_cus(world: int, fake: int) -> int:
-    """Compute units the channelizer's persistent grid leaves free (cfg.reserved_cus).  Built for the record gather of
-    N > 1 -- so that the RCCL kernels, the de-duplication and the record download would not wait for a channelizer
-    launch to end -- and measured in the 8-rank rehearsal (profiles/r4_fake_world.txt): it costs what it reserves (8 CUs:
-    + 1-2.6 % on the headline step) and buys nothing, because the runtime's copy kernels spread over whatever is free between
-    two launches either way.  Default 0 at every N; SNOUT_BENCH_RESERVED_CUS sets it."""
+    """Compute units the channelizer's persistent grid leaves free (cfg.reserved_cus).
+
+    N = 1 (and the one-GPU rehearsal of rank 0's load): 0 -- measured (profiles/r4_fake_world.txt, r6_fake_world.txt): reserving
+    costs what it reserves (8 CUs: + 0.8 % on the headline step, 16: + 3 %) and buys nothing, because everything rank 0 runs
+    for the exchange there (pack, de-duplication, blit downloads) is work of ITS OWN that fits between or beside two launches.
+
+    N > 1: 8, by construction -- it cannot be measured on a one-GPU pool.  An RCCL collective is a kernel on EVERY rank that
+    completes only while its peers' kernels run too, and a rank's kernel is dispatched when that rank has a CU free: with
+    every CU held by a persistent channelizer workgroup that is the ~0.1 ms between two launches, at a phase of the 2.5 ms
+    step that no other rank shares.  A collective kernel that started in rank A's gap then holds its CUs, spinning, until
+    rank B reaches its own gap -- across A's next channelizer launch, whose last workgroups wait for those CUs and finish a
+    launch late.  Eight CUs (one per RCCL channel: NCCL_MAX_NCHANNELS=8 below) left out of the grid let the collectives run
+    whenever they are launched.  SNOUT_BENCH_RESERVED_CUS overrides."""
     e = os.environ.get("SNOUT_BENCH_RESERVED_CUS")
-    return int(e) if e is not None else 0
+    if e is not None:
+        return int(e)
+    return 8 if world > 1 else 0
 
 
 # ------------------------------------------------------------------------------------------------

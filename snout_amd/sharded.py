@@ -59,6 +59,13 @@ class ShardedScan:
         self.depth = max(1, min(3, int(depth)))                       # submissions in flight per handle (the library holds 3)
         if self.batch > 1:
             rx_kw = dict(rx_kw, batch_segments=self.batch)
+        if n_channels > 1 and "reserved_cus" not in rx_kw:
+            # One rank of several on the RCCL backend: the record gather's collectives complete only while the peers' kernels
+            # run too, so they must not have to wait for a gap between two persistent channelizer launches that no other
+            # rank shares -- eight CUs (one per RCCL channel) stay out of the channelizer's grid
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1 and tdist.get_backend() == "nccl":
+                rx_kw = dict(rx_kw, reserved_cus=8)
         self.rxs = [SnoutRx(proto=proto, channel=channel, n_channels=n_channels, device=device, **rx_kw)
                     for _ in range(max(1, handles))]
         self.rx = self.rxs[0]
